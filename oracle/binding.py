@@ -1,0 +1,241 @@
+"""ctypes bindings for the oracle (oracle/liboracle.so) and, when built, for the compiled
+reference (oracle/_ref/libvmaf_ref_feature.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORDER_SCALAR, ORDER_AVX = 0, 1
+
+# insertion order of wrapper/src/combo.c:260-364
+ATOM_NAMES = (["adm_num", "adm_den"] +
+              [f"adm_{k}_scale{s}" for s in range(4) for k in ("num", "den")] +
+              ["motion"] +
+              [f"vif_{k}_scale{s}" for s in range(4) for k in ("num", "den")] +
+              ["vif"])
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_lib = None
+_ref = False
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def lib():
+    """Load (building if necessary) this repo's C restatement."""
+    global _lib
+    if _lib is None:
+        so = os.path.join(HERE, "liboracle.so")
+        src = os.path.join(HERE, "vmaf_oracle.c")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+            subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+        L = C.CDLL(so)
+        L.oracle_conv_sep.argtypes = [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_conv_sep.restype = None
+        L.oracle_vif.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        L.oracle_adm.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        L.oracle_sad.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_sad.restype = C.c_double
+        L.oracle_frame.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _dp]
+        L.oracle_vif_filter.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.oracle_vif_filter.restype = _fp
+        L.oracle_motion_filter.restype = _fp
+        L.oracle_adm_csf_rfactors.argtypes = [_fp]
+        L.oracle_log2f_approx.argtypes = [C.c_float]
+        L.oracle_log2f_approx.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The reference's own C sources, compiled by `make -C oracle ref`.  None when absent."""
+    global _ref
+    if _ref is False:
+        so = os.path.join(HERE, "_ref", "libvmaf_ref_feature.so")
+        if not os.path.exists(so):
+            _ref = None
+        else:
+            R = C.CDLL(so)
+            R.compute_vif.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+            R.compute_adm.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double]
+            R.compute_motion.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+            R.convolution_f32_c_s.argtypes = [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
+            R.convolution_f32_c_s.restype = None
+            R.ref_set_cpu.argtypes = [C.c_int]
+            _ref = R
+    return _ref
+
+
+def ref_exec_path():
+    p = os.path.join(HERE, "_ref", "vmafossexec")
+    return p if os.path.exists(p) else None
+
+
+# ------------------------------------------------------------------ oracle wrappers
+def vif_filter(scale):
+    n = C.c_int()
+    p = lib().oracle_vif_filter(scale, C.byref(n))
+    return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+def motion_filter():
+    return np.ctypeslib.as_array(lib().oracle_motion_filter(), shape=(5,)).copy()
+
+
+def csf_rfactors():
+    out = np.zeros(8, np.float32)
+    lib().oracle_adm_csf_rfactors(_ptr(out.reshape(1, 8)))
+    return out
+
+
+def conv_sep(filt, src, order=ORDER_SCALAR):
+    src = _f32(src)
+    filt = np.ascontiguousarray(filt, np.float32)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    lib().oracle_conv_sep(filt.ctypes.data_as(_fp), len(filt), _ptr(src), _ptr(dst), w, h, w, w, order)
+    return dst
+
+
+def vif(ref_off, dis_off, order=ORDER_SCALAR):
+    """-> (score, num, den, scores[8]) for already offset (-128) planes."""
+    r, d = _f32(ref_off), _f32(dis_off)
+    h, w = r.shape
+    s, n, dn = C.c_double(), C.c_double(), C.c_double()
+    sc = np.zeros(8)
+    rc = lib().oracle_vif(_ptr(r), _ptr(d), w, h, w, order, C.byref(s), C.byref(n), C.byref(dn),
+                          sc.ctypes.data_as(_dp))
+    assert rc == 0
+    return s.value, n.value, dn.value, sc
+
+
+def adm(ref_off, dis_off, exact_rcp=0):
+    r, d = _f32(ref_off), _f32(dis_off)
+    h, w = r.shape
+    s, n, dn = C.c_double(), C.c_double(), C.c_double()
+    sc = np.zeros(8)
+    rc = lib().oracle_adm(_ptr(r), _ptr(d), w, h, w, exact_rcp, C.byref(s), C.byref(n), C.byref(dn),
+                          sc.ctypes.data_as(_dp))
+    assert rc == 0
+    return s.value, n.value, dn.value, sc
+
+
+def sad(a, b):
+    a, b = _f32(a), _f32(b)
+    h, w = a.shape
+    return lib().oracle_sad(_ptr(a), _ptr(b), w, h, w, w)
+
+
+def frame(ref_raw, dis_raw, prev_blur, first, order=ORDER_SCALAR):
+    r, d = _f32(ref_raw), _f32(dis_raw)
+    h, w = r.shape
+    atoms = np.zeros(20)
+    rc = lib().oracle_frame(_ptr(r), _ptr(d), w, h, w, _ptr(prev_blur), int(first), order,
+                            atoms.ctypes.data_as(_dp))
+    assert rc == 0
+    return atoms
+
+
+def clip_atoms(ref_frames, dis_frames, order=ORDER_SCALAR):
+    """Per-frame loop of wrapper/src/combo.c:147-371 over un-offset luma planes [F,h,w] -> [F,20]."""
+    F = len(ref_frames)
+    h, w = ref_frames[0].shape
+    prev = np.zeros((h, w), np.float32)
+    out = np.zeros((F, 20))
+    for i in range(F):
+        out[i] = frame(ref_frames[i], dis_frames[i], prev, i == 0, order)
+    return out
+
+
+# ------------------------------------------------------------------ compiled-reference wrappers
+def _stride32(w):
+    b = w * 4
+    return b + ((32 - b % 32) % 32)   # ALIGN_CEIL, feature/src/common/alloc.h:24-27
+
+
+def _padded(a):
+    """Copy into a 32-byte aligned, 32-byte-row-stride buffer as combo.c:106-144 allocates."""
+    a = _f32(a)
+    h, w = a.shape
+    sp = _stride32(w) // 4
+    raw = np.zeros(h * sp + 16, np.float32)
+    off = (-raw.ctypes.data % 32) // 4
+    buf = raw[off:off + h * sp].reshape(h, sp)
+    buf[:, :w] = a
+    return buf, sp * 4
+
+
+def ref_conv_sep(filt, src, avx):
+    R = ref_lib()
+    R.ref_set_cpu(1 if avx else 0)
+    filt = np.ascontiguousarray(filt, np.float32)
+    s, sb = _padded(src)
+    h, w = np.asarray(src).shape
+    d, _ = _padded(np.zeros((h, w), np.float32))
+    t, _ = _padded(np.zeros((h, w + 8), np.float32))
+    R.convolution_f32_c_s(filt.ctypes.data_as(_fp), len(filt), _ptr(s), _ptr(d), _ptr(t), w, h, sb // 4, sb // 4)
+    return d[:, :w].copy()
+
+
+def ref_vif(ref_off, dis_off, avx):
+    R = ref_lib()
+    R.ref_set_cpu(1 if avx else 0)
+    r, sb = _padded(ref_off)
+    d, _ = _padded(dis_off)
+    h, w = np.asarray(ref_off).shape
+    s, n, dn = C.c_double(), C.c_double(), C.c_double()
+    sc = np.zeros(8)
+    rc = R.compute_vif(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(s), C.byref(n), C.byref(dn), sc.ctypes.data_as(_dp))
+    assert rc == 0
+    return s.value, n.value, dn.value, sc
+
+
+def ref_adm(ref_off, dis_off):
+    R = ref_lib()
+    r, sb = _padded(ref_off)
+    d, _ = _padded(dis_off)
+    h, w = np.asarray(ref_off).shape
+    s, n, dn = C.c_double(), C.c_double(), C.c_double()
+    sc = np.zeros(8)
+    rc = R.compute_adm(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(s), C.byref(n), C.byref(dn),
+                       sc.ctypes.data_as(_dp), 0.1)
+    assert rc == 0
+    return s.value, n.value, dn.value, sc
+
+
+def ref_clip_atoms(ref_frames, dis_frames, avx):
+    """The loop body of wrapper/src/combo.c:236-364 driven through the compiled reference."""
+    R = ref_lib()
+    R.ref_set_cpu(1 if avx else 0)
+    F = len(ref_frames)
+    h, w = ref_frames[0].shape
+    f5 = motion_filter()
+    out = np.zeros((F, 20))
+    prev = None
+    for i in range(F):
+        r = np.asarray(ref_frames[i], np.float32) + np.float32(-128)
+        d = np.asarray(dis_frames[i], np.float32) + np.float32(-128)
+        _, n, dn, sc = ref_adm(r, d)
+        out[i, 0], out[i, 1], out[i, 2:10] = n, dn, sc
+        blur = ref_conv_sep(f5, r, avx)
+        if i > 0:
+            a, sb = _padded(prev)
+            b, _ = _padded(blur)
+            m = C.c_double()
+            R.compute_motion(_ptr(a), _ptr(b), w, h, sb, sb, C.byref(m))
+            out[i, 10] = m.value
+        prev = blur
+        s, _, _, sc = ref_vif(r, d, avx)
+        out[i, 11:19], out[i, 19] = sc, s
+    return out
