@@ -1,0 +1,57 @@
+/*
+ * libvmaf.h - the library-level drop-in boundary of the MI355X VMAF engine.
+ *
+ * compute_vmaf() has the signature, argument meaning, stdout lines and log files of the
+ * reference's wrapper/src/libvmaf.h:26 (implementation wrapper/src/libvmaf.cpp:28-67 ->
+ * wrapper/src/vmaf.cpp:631-753): a program linked against the reference's libvmaf.a
+ * (wrapper/src/main.cpp:109, FFmpeg's libvmaf filter) links against libvmaf_amd.so unchanged.
+ *
+ *   fmt            yuv420p yuv422p yuv444p yuv420p10le yuv422p10le yuv444p10le (informational here,
+ *                  as in the reference where it only selects the PSNR peak, combo.c:171-186)
+ *   read_frame     called on the caller's thread, once per frame, in order; writes UN-OFFSET luma as
+ *                  fp32 in 8-bit units into ref_data / main_data (rows stride_byte apart,
+ *                  stride_byte = 4*width rounded up to 32); temp_data is 2 planes of scratch.
+ *                  Returns 0 = frame delivered, 2 = end of stream, 1 = failure (combo.c:149-157)
+ *   model_path     <name>.pkl (protocol-0 pickle); the libsvm model is read from <model_path>.model
+ *   log_path       NULL = no log; log_fmt "json" = JSON, anything else = XML (vmaf.cpp:675-750)
+ *   disable_avx    accepted and ignored (there is no CPU convolution path in this build)
+ *   enable_transform | phone_model   apply the model's score_transform (libvmaf.cpp:37-39)
+ *   do_psnr / do_ssim / do_ms_ssim   not features of vmaf_v0.6.1 and not built here: non-zero is an error
+ *   pool_method    NULL | "mean" | "min" | "harmonic_mean"
+ * Returns the pooled VMAF score.  Failures are reported as in the reference, by a C++ exception
+ * derived from std::exception (wrapper/src/vmaf.h:144-151) that wrapper/src/main.cpp:219-230 catches.
+ *
+ * Frames are gathered into batches, shipped to the GPU(s) and scored by the kernels behind
+ * include/vmaf_hip.h.  Environment knobs: VMAF_HIP_DEVICES="0,1,.." (default "0"), VMAF_HIP_BATCH=N.
+ */
+#ifndef LIBVMAF_H_
+#define LIBVMAF_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+double compute_vmaf(char* fmt, int width, int height, int (*read_frame)(float *ref_data, float *main_data, float *temp_data, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method);
+
+/*
+ * Same call for callers that cannot catch C++ exceptions (C programs, cgo/ctypes/JNI bindings).
+ * No counterpart in the reference (its compute_vmaf lets exceptions escape the extern "C" frame,
+ * libvmaf.cpp:63).  Returns 0 and stores the pooled score in *score, or returns non-zero and copies
+ * the message into errbuf (when errbuf != NULL).
+ */
+int compute_vmaf_noexcept(double *score, char* fmt, int width, int height, int (*read_frame)(float *ref_data, float *main_data, float *temp_data, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len);
+
+/*
+ * Fusion half only (wrapper/src/vmaf.cpp:351-559): atoms [nframes][20] (layout in vmaf_hip.h) ->
+ * per-frame VMAF scores and the derived feature vectors named by the model, in model order
+ * (features_out: [nframes][n_features], may be NULL).  The SVR runs on `device`.  Returns 0 on success.
+ */
+int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip,
+                                int enable_transform, int device, double *vmaf_out, double *features_out,
+                                char *errbuf, int errbuf_len);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* LIBVMAF_H_ */

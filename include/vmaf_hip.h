@@ -1,0 +1,119 @@
+/*
+ * vmaf_hip.h - thin C-ABI over the hand-written gfx950 (MI355X) HIP kernels of the VMAF v0.6.1
+ * feature-extraction + fusion hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * These entry points are what a host layer binds INSTEAD of the reference's per-frame C feature
+ * functions; each cites the reference interface it replaces (paths relative to the reference repo).
+ * The library-level drop-in, compute_vmaf(), is declared in include/libvmaf.h.
+ *
+ * Atom row layout (VMAF_HIP_ATOMS = 20 doubles per frame) is the insertion order of
+ * wrapper/src/combo.c:260-364:
+ *   [0] adm_num [1] adm_den [2..9] adm_{num,den}_scale0..3 [10] motion
+ *   [11..18] vif_{num,den}_scale0..3 [19] vif
+ *
+ * Error convention: functions return 0 on success, non-zero on failure (the convention of the
+ * reference's C feature functions, combo.c:240-243); vmaf_hip_last_error() gives the message.
+ * Nothing here falls back to a CPU path: without a usable HIP device every call fails.
+ */
+#ifndef VMAF_HIP_H_
+#define VMAF_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMAF_HIP_ATOMS 20
+
+typedef struct vmaf_hip_engine vmaf_hip_engine;
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char *vmaf_hip_last_error(void);
+
+/* Number of HIP devices visible (0 when there is none / no driver). */
+int vmaf_hip_device_count(void);
+
+/*
+ * One engine = one GPU, one frame geometry, one video stream's motion state.
+ * Replaces the per-video buffers combo() allocates (wrapper/src/combo.c:100-144) and the per-frame
+ * work areas of compute_vif (feature/src/vif.c:104) and compute_adm (feature/src/adm.c:101):
+ * everything is allocated once here and stays resident in HBM.
+ * max_batch = most frames a single extract call may carry (device scratch scales with it).
+ */
+int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int height, int max_batch);
+void vmaf_hip_engine_destroy(vmaf_hip_engine *e);
+
+/*
+ * Extract the 20 atoms of `nframes` CONSECUTIVE frames.  Replaces, per frame, the body of the
+ * reference loop wrapper/src/combo.c:236-364:
+ *   offset_image(-128) x2          (feature/src/common/file_io.c:177-198)
+ *   compute_adm(...)               (feature/src/adm.c:51, prototype combo.c:41)
+ *   convolution_f32_c(FILTER_5..)  (feature/src/common/convolution.c:78) + compute_motion (motion.c:65)
+ *   compute_vif(...)               (feature/src/vif.c:43, prototype combo.c:45)
+ * Inputs are UN-OFFSET fp32 luma planes exactly as a read_frame callback delivers them
+ * (8-bit units, libvmaf.h read_frame contract): frame f starts at base + f*frame_stride_bytes,
+ * rows are row_stride_bytes apart (multiple of 4).
+ * continue_sequence = 0: frame 0 of this call starts a video (motion = 0, combo.c:312-315);
+ *                   = 1: frame 0 follows the last frame of the previous call on this engine (or the
+ *                        frame given to vmaf_hip_motion_seed_*), whose blurred ref is still in HBM.
+ * atoms_out: HOST pointer, nframes * VMAF_HIP_ATOMS doubles.
+ * _device: ref/dis are device pointers on the engine's GPU.  _host: host pointers (staged by the engine).
+ */
+int vmaf_hip_extract_device(vmaf_hip_engine *e, const float *d_ref, const float *d_dis,
+                            size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                            int continue_sequence, double *atoms_out);
+int vmaf_hip_extract_host(vmaf_hip_engine *e, const float *h_ref, const float *h_dis,
+                          size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                          int continue_sequence, double *atoms_out);
+
+/*
+ * Asynchronous form of vmaf_hip_extract_device for benchmarking and pipelining: enqueue only;
+ * atoms land in atoms_out (host, ideally pinned) once vmaf_hip_engine_sync() returns.
+ */
+int vmaf_hip_extract_device_async(vmaf_hip_engine *e, const float *d_ref, const float *d_dis,
+                                  size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                                  int continue_sequence, double *atoms_out);
+int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const float *h_dis,
+                                size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                                int continue_sequence, double *atoms_out);
+int vmaf_hip_engine_sync(vmaf_hip_engine *e);
+
+/*
+ * Page-locked host memory for read_frame buffers, so that the H2D copies of
+ * vmaf_hip_extract_host_async really are asynchronous.  Replaces aligned_malloc for the frame
+ * buffers of combo() (wrapper/src/combo.c:116-144, feature/src/common/alloc.h); 4096-byte aligned.
+ */
+void *vmaf_hip_host_alloc(size_t bytes);
+void vmaf_hip_host_free(void *p);
+
+/*
+ * Motion halo for frame-range sharding: blur one ref frame (the frame just before this shard's
+ * first frame) into the engine's "previous blurred frame" slot, so that the next extract call with
+ * continue_sequence = 1 gets an exact motion value for its first frame.  Replaces the carried
+ * prev_blur_buf state of combo.c:309-326.
+ */
+int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t row_stride_bytes);
+int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row_stride_bytes);
+
+/*
+ * Batched nu-SVR RBF prediction.  Replaces the per-frame svm_predict() call site
+ * wrapper/src/vmaf.cpp:468 (wrapper/src/svm.cpp:305 -> :229 -> k_function RBF :179-219):
+ *   out[f] = sum_i coef[i] * exp(-gamma * |x[f] - sv[i]|^2) - rho        (all fp64)
+ * sv is dense [n_sv][dim] (entries omitted from the sparse libsvm text are 0), x is [n][dim].
+ * All pointers are HOST pointers.
+ */
+int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n_sv, int dim,
+                         double gamma, double rho, const double *x, int n, double *out);
+
+/*
+ * Kernel-level timing hook for bench.py: HIP-event time in milliseconds of the LAST extract call's
+ * kernels, measured on the engine's own stream.  which: 0 = whole batch, 1 = VIF scale-0 statistic
+ * kernel (the dominant kernel).  Returns < 0 when nothing has run.
+ */
+double vmaf_hip_last_kernel_ms(vmaf_hip_engine *e, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMAF_HIP_H_ */

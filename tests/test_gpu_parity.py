@@ -1,0 +1,164 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (vmaf_amd/libvmaf_amd.so), against
+the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): per-frame features within 1e-4 absolute of the reference C
+code, aggregate VMAF within 1e-3.  The kernels keep the reference's scalar tap order, so the raw
+atoms are additionally held to 2e-6 relative (only the final plane sums are ordered differently).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import vmaf_amd
+from vmaf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FEATURE_TOL = 1e-4
+ATOM_RTOL = 2e-6
+
+
+def _feats(atoms):
+    return oracle.derived_features(atoms)
+
+
+def _check(got, want, what=""):
+    # raw atoms: relative (values span 1e0 .. 1e6); motion absolute
+    for k, name in enumerate(vmaf_amd.ATOM_NAMES):
+        g, w = got[:, k], want[:, k]
+        tol = ATOM_RTOL * np.maximum(1.0, np.abs(w))
+        assert np.all(np.abs(g - w) <= tol), f"{what} atom {name}: got {g} want {w}"
+    fg, fw = _feats(got), _feats(want)
+    for k in ("adm2", "motion", "motion2", "vif_scale0", "vif_scale1", "vif_scale2", "vif_scale3",
+              "adm_scale0", "adm_scale1", "adm_scale2", "adm_scale3", "vif"):
+        assert np.all(np.abs(fg[k] - fw[k]) <= FEATURE_TOL), f"{what} feature {k}: {fg[k]} vs {fw[k]}"
+
+
+def _clip(w, h, frames, bits=8, **kw):
+    r, d = synth.make_clip(w, h, frames, bits=bits, **kw)
+    return synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+
+
+@pytest.mark.parametrize("w,h,frames", [(64, 48, 5), (577, 325, 3), (576, 324, 3), (200, 32, 2), (33, 130, 2), (1920, 1080, 2)])
+def test_atoms_match_oracle(w, h, frames):
+    ref, dis = _clip(w, h, frames, seed=w + h)
+    want = oracle.clip_atoms(ref, dis, oracle.ORDER_SCALAR)
+    with vmaf_amd.Engine(w, h, max_batch=4) as e:
+        got = e.extract(ref, dis)
+    _check(got, want, f"{w}x{h}")
+
+
+def test_ten_bit_input():
+    ref, dis = _clip(320, 180, 3, bits=10, seed=5)
+    assert np.any(ref != np.round(ref))            # quarter steps really present
+    want = oracle.clip_atoms(ref, dis)
+    with vmaf_amd.Engine(320, 180, max_batch=8) as e:
+        got = e.extract(ref, dis)
+    _check(got, want, "10-bit")
+
+
+def test_batch_size_does_not_change_results():
+    ref, dis = _clip(160, 96, 9, seed=3, cuts=(4,))
+    with vmaf_amd.Engine(160, 96, max_batch=9) as e:
+        whole = e.extract(ref, dis)
+    with vmaf_amd.Engine(160, 96, max_batch=2) as e:
+        pieces = e.extract(ref, dis)
+    assert np.array_equal(whole, pieces)
+    _check(whole, oracle.clip_atoms(ref, dis), "cuts")
+
+
+def test_motion_halo_matches_unsharded_run():
+    """Frame-range sharding: a shard seeded with the frame before it reproduces the
+    unsharded motion values bit for bit, including across a scene cut at the shard edge."""
+    ref, dis = _clip(192, 112, 8, seed=11, cuts=(4,))
+    with vmaf_amd.Engine(192, 112, max_batch=8) as e:
+        whole = e.extract(ref, dis)
+    for start in (3, 4, 5):
+        with vmaf_amd.Engine(192, 112, max_batch=8) as e:
+            e.motion_seed(ref[start - 1])
+            shard = e.extract(ref[start:], dis[start:], continue_sequence=True)
+        assert np.array_equal(shard, whole[start:]), f"shard from {start}"
+
+
+def test_static_and_identical_clip():
+    ref, _ = _clip(128, 80, 3, seed=2, static=True)
+    want = oracle.clip_atoms(ref, ref)
+    with vmaf_amd.Engine(128, 80) as e:
+        got = e.extract(ref, ref)
+    _check(got, want, "identical")
+    assert np.all(got[:, 10] == 0.0)               # static clip: motion exactly 0
+    f = _feats(got)
+    assert np.all(np.abs(f["adm2"] - 1.0) < 1e-6)
+
+
+def test_flat_frames():
+    """Reference corner case python/test/feature_test.py:659-719 (flat Y=0 vs Y=10), at reduced size."""
+    ref = np.zeros((2, 72, 128), np.float32)
+    dis = np.full((2, 72, 128), 10.0, np.float32)
+    want = oracle.clip_atoms(ref, dis)
+    with vmaf_amd.Engine(128, 72) as e:
+        got = e.extract(ref, dis)
+    fg, fw = _feats(got), _feats(want)
+    for k in ("adm2", "vif_scale0", "vif_scale1", "vif_scale2", "vif_scale3", "motion2"):
+        assert np.all(np.abs(fg[k] - fw[k]) <= FEATURE_TOL), k
+    assert np.allclose(got[:, 11], 128 * 72)       # vif_num_scale0 == pixel count (feature_test.py:702)
+
+
+def test_device_pointer_entry_matches_host_entry():
+    torch = pytest.importorskip("torch")
+    ref, dis = _clip(256, 144, 4, seed=9)
+    with vmaf_amd.Engine(256, 144, max_batch=4) as e:
+        host = e.extract(ref, dis)
+    tr, td = torch.from_numpy(ref).cuda(), torch.from_numpy(dis).cuda()
+    torch.cuda.synchronize()
+    with vmaf_amd.Engine(256, 144, max_batch=4) as e:
+        dev = e.extract_device(tr, td, 4)
+    assert np.array_equal(host, dev)
+
+
+def test_svm_predict_matches_oracle(model_path):
+    svm = oracle.load_svm_model(model_path + ".model")
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.2, 1.2, (37, 6))
+    want = oracle.svm_predict(svm, x)
+    got = vmaf_amd.svm_predict(svm["sv"], svm["coef"], svm["gamma"], svm["rho"], x)
+    assert np.all(np.abs(got - want) < 1e-10)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(phone_model=True), dict(disable_clip=True), dict(pool_method="harmonic_mean"),
+                                dict(pool_method="min")])
+def test_compute_vmaf_end_to_end(model_path, tmp_path, kw):
+    ref, dis = _clip(320, 180, 6, seed=21, cuts=(3,))
+    atoms = oracle.clip_atoms(ref, dis)
+    pkl, svm = oracle.load_pkl_model(model_path), oracle.load_svm_model(model_path + ".model")
+    per_frame, feats = oracle.vmaf_from_atoms(atoms, pkl, svm, enable_transform=kw.get("phone_model", False),
+                                              disable_clip=kw.get("disable_clip", False))
+    from oracle.fusion import pool
+    want = pool(per_frame, kw.get("pool_method"))
+    log = str(tmp_path / "log.json")
+    got = vmaf_amd.compute_vmaf_from_arrays(ref, dis, model_path=model_path, log_path=log, log_fmt="json", **kw)
+    assert abs(got - want) < 1e-3
+    import json
+    doc = json.load(open(log))
+    assert doc["metrics"] == ["adm2", "motion2", "vif_scale0", "vif_scale1", "vif_scale2", "vif_scale3", "vmaf"]
+    assert len(doc["frames"]) == 6
+    for i, fr in enumerate(doc["frames"]):
+        assert fr["frameNum"] == i
+        assert abs(fr["metrics"]["vmaf"] - per_frame[i]) < 1e-3
+        for k in ("adm2", "motion2", "vif_scale0", "vif_scale1", "vif_scale2", "vif_scale3"):
+            assert abs(fr["metrics"][k] - feats[k][i]) < FEATURE_TOL + 1e-5   # log rounds to 5 decimals
+
+
+def test_error_paths(model_path):
+    with pytest.raises(vmaf_amd.VmafHipError):
+        vmaf_amd.Engine(8, 8)
+    ref, dis = _clip(64, 48, 1)
+    with pytest.raises(vmaf_amd.VmafHipError, match="model"):
+        vmaf_amd.compute_vmaf_from_arrays(ref, dis, model_path="/nonexistent.pkl")
+    with pytest.raises(vmaf_amd.VmafHipError, match="psnr"):
+        vmaf_amd.compute_vmaf_from_arrays(ref, dis, model_path=model_path, do_psnr=True)
+    with vmaf_amd.Engine(64, 48) as e:
+        with pytest.raises(vmaf_amd.VmafHipError, match="previous frame"):
+            e.extract(ref, dis, continue_sequence=True)

@@ -1,0 +1,222 @@
+"""ctypes bindings of vmaf_amd/libvmaf_amd.so (include/vmaf_hip.h, include/libvmaf.h).
+
+Fails loudly: a missing library raises VmafHipError at first use; nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+DEFAULT_MODEL = os.path.join(REPO, "model", "vmaf_v0.6.1.pkl")
+
+# insertion order of the reference's wrapper/src/combo.c:260-364
+ATOM_NAMES = (["adm_num", "adm_den"] +
+              [f"adm_{k}_scale{s}" for s in range(4) for k in ("num", "den")] +
+              ["motion"] +
+              [f"vif_{k}_scale{s}" for s in range(4) for k in ("num", "den")] +
+              ["vif"])
+N_ATOMS = 20
+
+
+class VmafHipError(RuntimeError):
+    pass
+
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+READ_FRAME = C.CFUNCTYPE(C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p)
+_lib = None
+
+
+def library_path():
+    return os.path.join(HERE, "libvmaf_amd.so")
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise VmafHipError(f"{path} is missing: build it with `make -C vmaf_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.vmaf_hip_last_error.restype = C.c_char_p
+    L.vmaf_hip_device_count.restype = i
+    L.vmaf_hip_engine_create.argtypes = [C.POINTER(vp), i, i, i, i]
+    L.vmaf_hip_engine_destroy.argtypes = [vp]
+    L.vmaf_hip_engine_destroy.restype = None
+    for name in ("vmaf_hip_extract_device", "vmaf_hip_extract_host", "vmaf_hip_extract_device_async",
+                 "vmaf_hip_extract_host_async"):
+        getattr(L, name).argtypes = [vp, vp, vp, sz, sz, i, i, _dp]
+    L.vmaf_hip_engine_sync.argtypes = [vp]
+    L.vmaf_hip_host_alloc.argtypes = [sz]
+    L.vmaf_hip_host_alloc.restype = vp
+    L.vmaf_hip_host_free.argtypes = [vp]
+    L.vmaf_hip_host_free.restype = None
+    L.vmaf_hip_motion_seed_device.argtypes = [vp, vp, sz]
+    L.vmaf_hip_motion_seed_host.argtypes = [vp, vp, sz]
+    L.vmaf_hip_svm_predict.argtypes = [i, _dp, _dp, i, i, C.c_double, C.c_double, _dp, i, _dp]
+    L.vmaf_hip_last_kernel_ms.argtypes = [vp, i]
+    L.vmaf_hip_last_kernel_ms.restype = C.c_double
+    L.compute_vmaf_noexcept.argtypes = [_dp, C.c_char_p, i, i, READ_FRAME, vp, C.c_char_p, C.c_char_p, C.c_char_p,
+                                        i, i, i, i, i, i, i, C.c_char_p, C.c_char_p, i]
+    L.vmaf_amd_predict_from_atoms.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, C.c_char_p, i]
+    _lib = L
+    return L
+
+
+def _err(L):
+    return (L.vmaf_hip_last_error() or b"").decode(errors="replace")
+
+
+def device_count():
+    return load_library().vmaf_hip_device_count()
+
+
+class Engine:
+    """One GPU, one frame geometry, one video's motion state (vmaf_hip_engine)."""
+
+    def __init__(self, width, height, max_batch=16, device=0):
+        self.L = load_library()
+        self.w, self.h, self.max_batch, self.device = width, height, max_batch, device
+        h = C.c_void_p()
+        if self.L.vmaf_hip_engine_create(C.byref(h), device, width, height, max_batch):
+            raise VmafHipError(_err(self.L))
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.vmaf_hip_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- host arrays ------------------------------------------------------------------------
+    def extract(self, ref, dis, continue_sequence=False):
+        """ref, dis: float32 numpy [F,h,w] un-offset luma (8-bit units).  -> atoms [F,20]."""
+        ref = np.ascontiguousarray(ref, np.float32)
+        dis = np.ascontiguousarray(dis, np.float32)
+        if ref.ndim == 2:
+            ref, dis = ref[None], dis[None]
+        F, h, w = ref.shape
+        if (h, w) != (self.h, self.w) or dis.shape != ref.shape:
+            raise VmafHipError(f"shape {ref.shape}/{dis.shape} does not match engine {self.h}x{self.w}")
+        out = np.zeros((F, N_ATOMS))
+        done = 0
+        while done < F:
+            n = min(self.max_batch, F - done)
+            if self.L.vmaf_hip_extract_host(self._h, ref[done:].ctypes.data, dis[done:].ctypes.data, w * 4, w * h * 4, n,
+                                            1 if (continue_sequence or done) else 0, out[done:].ctypes.data_as(_dp)):
+                raise VmafHipError(_err(self.L))
+            done += n
+        return out
+
+    # -- device pointers (torch tensors or raw ints) ----------------------------------------------
+    def extract_device(self, d_ref, d_dis, nframes, row_stride_bytes=None, frame_stride_bytes=None,
+                       continue_sequence=False, out=None, sync=True):
+        """d_ref, d_dis: device addresses (int) or objects with data_ptr() (torch CUDA tensors)."""
+        pr = d_ref.data_ptr() if hasattr(d_ref, "data_ptr") else int(d_ref)
+        pd = d_dis.data_ptr() if hasattr(d_dis, "data_ptr") else int(d_dis)
+        rs = row_stride_bytes or self.w * 4
+        fs = frame_stride_bytes or rs * self.h
+        if out is None:
+            out = np.zeros((nframes, N_ATOMS))
+        fn = self.L.vmaf_hip_extract_device if sync else self.L.vmaf_hip_extract_device_async
+        if fn(self._h, pr, pd, rs, fs, nframes, 1 if continue_sequence else 0, out.ctypes.data_as(_dp)):
+            raise VmafHipError(_err(self.L))
+        self._keep = (d_ref, d_dis, out)
+        return out
+
+    def sync(self):
+        if self.L.vmaf_hip_engine_sync(self._h):
+            raise VmafHipError(_err(self.L))
+
+    def motion_seed(self, ref_frame):
+        """Blur one ref frame (numpy [h,w] float32, or a device address / torch tensor) as the motion halo."""
+        if hasattr(ref_frame, "data_ptr") or isinstance(ref_frame, int):
+            p = ref_frame.data_ptr() if hasattr(ref_frame, "data_ptr") else ref_frame
+            rc = self.L.vmaf_hip_motion_seed_device(self._h, p, self.w * 4)
+        else:
+            a = np.ascontiguousarray(ref_frame, np.float32)
+            rc = self.L.vmaf_hip_motion_seed_host(self._h, a.ctypes.data, self.w * 4)
+        if rc:
+            raise VmafHipError(_err(self.L))
+
+    def arm_timing(self):
+        self.L.vmaf_hip_last_kernel_ms(self._h, 0)
+
+    def last_kernel_ms(self, which=0):
+        return self.L.vmaf_hip_last_kernel_ms(self._h, which)
+
+
+def svm_predict(sv, coef, gamma, rho, x, device=0):
+    L = load_library()
+    sv = np.ascontiguousarray(sv, np.float64)
+    coef = np.ascontiguousarray(coef, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(len(x))
+    if L.vmaf_hip_svm_predict(device, sv.ctypes.data_as(_dp), coef.ctypes.data_as(_dp), sv.shape[0], sv.shape[1],
+                              gamma, rho, x.ctypes.data_as(_dp), len(x), out.ctypes.data_as(_dp)):
+        raise VmafHipError(_err(L))
+    return out
+
+
+def predict_from_atoms(atoms, model_path=DEFAULT_MODEL, disable_clip=False, enable_transform=False, device=0,
+                       n_features=6):
+    """atoms [F,20] -> (vmaf [F], features [F,n_features] in the model's feature order)."""
+    L = load_library()
+    atoms = np.ascontiguousarray(atoms, np.float64)
+    F = len(atoms)
+    vm = np.zeros(F)
+    feats = np.zeros((F, n_features))
+    err = C.create_string_buffer(1024)
+    if L.vmaf_amd_predict_from_atoms(model_path.encode(), atoms.ctypes.data_as(_dp), F, int(disable_clip),
+                                     int(enable_transform), device, vm.ctypes.data_as(_dp), feats.ctypes.data_as(_dp),
+                                     err, 1024):
+        raise VmafHipError(err.value.decode(errors="replace"))
+    return vm, feats
+
+
+def compute_vmaf_from_arrays(ref, dis, fmt="yuv420p", model_path=DEFAULT_MODEL, log_path=None, log_fmt=None,
+                             disable_clip=False, enable_transform=False, phone_model=False, pool_method=None,
+                             do_psnr=False, do_ssim=False, do_ms_ssim=False):
+    """Drive compute_vmaf() through its read_frame callback from float32 luma arrays [F,h,w]
+    (un-offset, 8-bit units) - the way an external C caller such as FFmpeg's libvmaf filter does."""
+    L = load_library()
+    ref = np.ascontiguousarray(ref, np.float32)
+    dis = np.ascontiguousarray(dis, np.float32)
+    F, h, w = ref.shape
+    state = {"i": 0}
+
+    def cb(rp, dp_, tp, stride, user):
+        i = state["i"]
+        if i >= F:
+            return 2
+        sp = stride // 4
+        r = np.ctypeslib.as_array(rp, shape=(h, sp))
+        d = np.ctypeslib.as_array(dp_, shape=(h, sp))
+        r[:, :w] = ref[i]
+        d[:, :w] = dis[i]
+        state["i"] = i + 1
+        return 0
+
+    score = C.c_double()
+    err = C.create_string_buffer(1024)
+    enc = lambda s: s.encode() if s is not None else None  # noqa: E731
+    rc = L.compute_vmaf_noexcept(C.byref(score), fmt.encode(), w, h, READ_FRAME(cb), None, model_path.encode(), enc(log_path),
+                                 enc(log_fmt), int(disable_clip), 0, int(enable_transform), int(phone_model), int(do_psnr),
+                                 int(do_ssim), int(do_ms_ssim), enc(pool_method), err, 1024)
+    if rc:
+        raise VmafHipError(err.value.decode(errors="replace"))
+    return score.value

@@ -1,0 +1,389 @@
+// libvmaf.cpp - host layer of the MI355X VMAF engine: compute_vmaf() (include/libvmaf.h).
+//
+// Mirrors the reference's wrapper: libvmaf.cpp:28-67 (flag handling) -> vmaf.cpp:631-753 (RunVmaf:
+// timer, pooling, stdout lines, XML/JSON logs) -> vmaf.cpp:140-624 (VmafRunner::run: model, per-frame
+// feature loop, derived features, normalise, SVR, de-normalise, transform, clip).  The per-frame C
+// feature functions and svm_predict are replaced by the kernels behind include/vmaf_hip.h.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/libvmaf.h"
+#include "../../include/vmaf_hip.h"
+#include "model.h"
+
+namespace {
+
+// wrapper/src/vmaf.h:144-151
+class VmafException : public std::exception {
+public:
+    explicit VmafException(const std::string &m) : msg(m) {}
+    const char *what() const noexcept override { return msg.c_str(); }
+private:
+    std::string msg;
+};
+
+constexpr int kAtoms = VMAF_HIP_ATOMS;
+
+struct EngineGuard {
+    std::vector<vmaf_hip_engine *> engines;
+    std::vector<void *> pinned;
+    ~EngineGuard()
+    {
+        for (auto e : engines) vmaf_hip_engine_destroy(e);
+        for (auto p : pinned) vmaf_hip_host_free(p);
+    }
+};
+
+std::vector<int> parse_devices()
+{
+    std::vector<int> d;
+    const char *env = std::getenv("VMAF_HIP_DEVICES");
+    if (env && *env) {
+        const char *p = env;
+        while (*p) {
+            char *end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            d.push_back((int)v);
+            p = (*end == ',') ? end + 1 : end;
+        }
+    }
+    if (d.empty()) d.push_back(0);
+    return d;
+}
+
+// The per-frame feature loop of combo() (wrapper/src/combo.c:100-371), batched: frames are pulled
+// serially through read_frame into page-locked buffers and dealt, a batch at a time, round-robin to
+// the engines (one per GPU); each batch after the first gets its motion halo from the previous
+// batch's last ref frame.  Fills atoms [frames][20].
+void extract_atoms(int (*read_frame)(float *, float *, float *, int, void *), void *user_data, int w, int h,
+                   std::vector<double> &atoms)
+{
+    if (w <= 0 || h <= 0) throw VmafException("wrong width " + std::to_string(w) + " or height " + std::to_string(h) + ".");
+    const size_t stride = ((size_t)w * 4 + 31) / 32 * 32;          // ALIGN_CEIL, combo.c:106
+    const size_t plane = stride * h;
+
+    const std::vector<int> devices = parse_devices();
+    const int G = (int)devices.size();
+    int batch = (int)std::min<size_t>(64, std::max<size_t>(4, ((size_t)128 << 20) / plane));
+    if (const char *env = std::getenv("VMAF_HIP_BATCH")) { const int v = std::atoi(env); if (v > 0) batch = std::min(v, 4096); }
+
+    EngineGuard guard;
+    struct Slot { float *ref[2], *dis[2]; int fill = 0; bool pending = false; size_t pend_start = 0; int pend_n = 0; std::vector<double> out; };
+    std::vector<Slot> slots(G);
+    for (int g = 0; g < G; ++g) {
+        vmaf_hip_engine *e = nullptr;
+        if (vmaf_hip_engine_create(&e, devices[g], w, h, batch)) throw VmafException(vmaf_hip_last_error());
+        guard.engines.push_back(e);
+        for (int b = 0; b < 2; ++b) {
+            float **pp[2] = { &slots[g].ref[b], &slots[g].dis[b] };
+            for (auto p : pp) {
+                *p = (float *)vmaf_hip_host_alloc(plane * batch);
+                if (!*p) throw VmafException(vmaf_hip_last_error());
+                guard.pinned.push_back(*p);
+            }
+        }
+        slots[g].out.resize((size_t)batch * kAtoms);
+    }
+    float *temp = (float *)vmaf_hip_host_alloc(plane * 2);        // combo.c:139-144
+    if (!temp) throw VmafException(vmaf_hip_last_error());
+    guard.pinned.push_back(temp);
+
+    auto collect = [&](int g) {
+        Slot &s = slots[g];
+        if (!s.pending) return;
+        if (vmaf_hip_engine_sync(guard.engines[g])) throw VmafException(vmaf_hip_last_error());
+        if (atoms.size() < (s.pend_start + s.pend_n) * kAtoms) atoms.resize((s.pend_start + s.pend_n) * kAtoms);
+        std::copy(s.out.begin(), s.out.begin() + (size_t)s.pend_n * kAtoms, atoms.begin() + s.pend_start * kAtoms);
+        s.pending = false;
+    };
+
+    size_t total = 0;
+    int g = 0;
+    const float *prev_last_ref = nullptr;                          // last ref frame of the previous batch (host)
+    bool eof = false;
+    while (!eof) {
+        Slot &s = slots[g];
+        float *rb = s.ref[s.fill], *db = s.dis[s.fill];
+        int n = 0;
+        while (n < batch) {
+            const int ret = read_frame((float *)((char *)rb + plane * n), (float *)((char *)db + plane * n), temp, (int)stride, user_data);
+            if (ret == 1) throw VmafException("read_frame failed.");   // combo.c:151-153
+            if (ret == 2) { eof = true; break; }
+            ++n;
+        }
+        if (n == 0) break;
+        collect(g);                                                // engine g is free again, its other buffer reusable
+        const bool cont = total > 0;
+        if (cont && G > 1) {
+            if (vmaf_hip_motion_seed_host(guard.engines[g], prev_last_ref, stride)) throw VmafException(vmaf_hip_last_error());
+        }
+        if (vmaf_hip_extract_host_async(guard.engines[g], rb, db, stride, plane, n, cont ? 1 : 0, s.out.data()))
+            throw VmafException(vmaf_hip_last_error());
+        s.pending = true; s.pend_start = total; s.pend_n = n;
+        s.fill ^= 1;
+        prev_last_ref = (const float *)((const char *)rb + plane * (n - 1));
+        total += n;
+        g = (g + 1) % G;
+    }
+    for (int i = 0; i < G; ++i) collect(i);
+    atoms.resize(total * kAtoms);
+}
+
+const char *kKnownFeatures[] = { "adm2", "adm_scale0", "adm_scale1", "adm_scale2", "adm_scale3", "motion", "vif_scale0",
+                                 "vif_scale1", "vif_scale2", "vif_scale3", "vif", "motion2" };
+
+// vmaf.cpp:399-427: "VMAF_feature_<name>_score" -> short name, or throw "Unknown feature name"
+std::string short_feature_name(const std::string &full)
+{
+    const std::string pre = "VMAF_feature_", post = "_score";
+    if (full.size() > pre.size() + post.size() && full.compare(0, pre.size(), pre) == 0 &&
+        full.compare(full.size() - post.size(), post.size(), post) == 0) {
+        const std::string mid = full.substr(pre.size(), full.size() - pre.size() - post.size());
+        for (auto k : kKnownFeatures) if (mid == k) return mid;
+    }
+    std::printf("Unknown feature name: '%s'.\n", full.c_str());
+    throw VmafException("Unknown feature name");
+}
+
+// vmaf.cpp:351-559
+void fuse(const vmaf_amd::VmafModel &model, const std::vector<double> &atoms, size_t F, bool disable_clip, bool enable_transform,
+          int device, std::vector<double> &vmaf, std::map<std::string, std::vector<double>> &feats)
+{
+    std::map<std::string, std::vector<double>> all;
+    for (auto k : kKnownFeatures) all[k].resize(F);
+    for (size_t i = 0; i < F; ++i) {
+        const double *a = &atoms[i * kAtoms];
+        all["adm2"][i] = a[0] / a[1];                              // ADM2_CONSTANT = 0, vmaf.cpp:358
+        for (int s = 0; s < 4; ++s) {
+            all["adm_scale" + std::to_string(s)][i] = a[2 + 2 * s] / a[3 + 2 * s];
+            all["vif_scale" + std::to_string(s)][i] = a[11 + 2 * s] / a[12 + 2 * s];
+        }
+        all["motion"][i] = a[10];
+        all["vif"][i] = a[19];
+    }
+    for (size_t i = 0; i + 1 < F; ++i) all["motion2"][i] = std::min(atoms[i * kAtoms + 10], atoms[(i + 1) * kAtoms + 10]);
+    if (F) all["motion2"][F - 1] = atoms[(F - 1) * kAtoms + 10];   // vmaf.cpp:375-379
+
+    const size_t D = model.feature_names.size();
+    std::vector<std::string> names;
+    for (auto &fn : model.feature_names) names.push_back(short_feature_name(fn));
+    std::vector<double> x(F * D);
+    for (size_t j = 0; j < D; ++j) {
+        const std::vector<double> &v = all[names[j]];
+        for (size_t i = 0; i < F; ++i)
+            x[i * D + j] = model.linear_rescale ? model.slopes[j + 1] * v[i] + model.intercepts[j + 1] : v[i];
+    }
+    vmaf.assign(F, 0.0);
+    if (F && vmaf_hip_svm_predict(device, model.sv.data(), model.coef.data(), model.n_sv, model.dim, model.gamma, model.rho,
+                                  x.data(), (int)F, vmaf.data()))
+        throw VmafException(vmaf_hip_last_error());
+    for (size_t i = 0; i < F; ++i) {
+        double p = vmaf[i];
+        if (model.linear_rescale) p = (p - model.intercepts[0]) / model.slopes[0];
+        if (enable_transform && model.transform.present) {        // vmaf.cpp:481-516
+            const vmaf_amd::ScoreTransform &t = model.transform;
+            double v = 0.0;
+            if (t.has_p0) v += t.p0;
+            if (t.has_p1) v += t.p1 * p;
+            if (t.has_p2) v += t.p2 * p * p;
+            if (t.out_lte_in && v > p) v = p;
+            if (t.out_gte_in && v < p) v = p;
+            p = v;
+        }
+        if (!disable_clip && model.has_clip) {                    // vmaf.cpp:519-529
+            if (p < model.clip_lo) p = model.clip_lo;
+            else if (p > model.clip_hi) p = model.clip_hi;
+        }
+        vmaf[i] = p;
+    }
+    feats.clear();
+    for (auto &n : names) feats[n] = all[n];
+}
+
+// vmaf.h:59-88
+double pool(const std::vector<double> &v, const char *method)
+{
+    if (method && std::strcmp(method, "min") == 0) {
+        double m = v[0];
+        for (double e : v) if (e < m) m = e;
+        return m;
+    }
+    if (method && std::strcmp(method, "harmonic_mean") == 0) {
+        double s = 0.0;
+        for (double e : v) s += 1.0 / (e + 1.0);
+        return 1.0 / (s / v.size()) - 1.0;
+    }
+    double s = 0.0;
+    for (double e : v) s += e;
+    return s / v.size();
+}
+
+std::string file_name_of(const std::string &s)                     // vmaf.cpp:767-778
+{
+    const size_t i = s.rfind('/');
+    return i == std::string::npos ? std::string("") : s.substr(i + 1);
+}
+
+std::string fmt_g(double v) { char b[64]; std::snprintf(b, sizeof b, "%g", v); return b; }   // pugixml double attribute
+
+std::string fmt_json(double v)                                     // ptools JSONPrint of a real_8
+{
+    char b[64];
+    std::snprintf(b, sizeof b, "%.16g", v);
+    std::string s = b;
+    if (s.find_first_of(".en") == std::string::npos) s += ".0";
+    return s;
+}
+
+double round5(double v)                                            // vmaf.cpp:755-765
+{
+    const double m = 100000.0;
+    const double x = v * m;
+    return (x < 0 ? std::ceil(x - 0.5) : std::floor(x + 0.5)) / m;
+}
+
+const char kLogVersion[] = "0.3.2";                                // vmaf.cpp:629
+
+void write_logs(const char *log_path, const char *log_fmt, const char *model_path, int width, int height, size_t F, double aggregate,
+                double exec_fps, const std::map<std::string, std::vector<double>> &result)
+{
+    FILE *fp = std::fopen(log_path, "w");
+    if (!fp) return;                                               // the reference ignores a failed log open too
+    const std::string model = file_name_of(model_path);
+    if (log_fmt && std::strcmp(log_fmt, "json") == 0) {           // vmaf.cpp:675-718
+        std::fprintf(fp, "{\n  \"version\":\"%s\",\n  \"params\":{\n    \"model\":\"%s\",\n    \"scaledWidth\":%d,\n    \"scaledHeight\":%d\n  },\n",
+                     kLogVersion, model.c_str(), width, height);
+        std::fprintf(fp, "  \"metrics\":[\n");
+        size_t k = 0;
+        for (auto &kv : result) std::fprintf(fp, "    \"%s\"%s\n", kv.first.c_str(), ++k < result.size() ? "," : "");
+        std::fprintf(fp, "  ],\n  \"frames\":[\n");
+        for (size_t i = 0; i < F; ++i) {
+            std::fprintf(fp, "    {\n      \"frameNum\":%zu,\n      \"metrics\":{\n", i);
+            k = 0;
+            for (auto &kv : result)
+                std::fprintf(fp, "        \"%s\":%s%s\n", kv.first.c_str(), fmt_json(round5(kv.second[i])).c_str(), ++k < result.size() ? "," : "");
+            std::fprintf(fp, "      }\n    }%s\n", i + 1 < F ? "," : "");
+        }
+        std::fprintf(fp, "  ]\n}\n");
+    } else {                                                       // vmaf.cpp:719-750
+        std::fprintf(fp, "<?xml version=\"1.0\"?>\n<VMAF version=\"%s\">\n", kLogVersion);
+        std::fprintf(fp, "\t<params model=\"%s\" scaledWidth=\"%d\" scaledHeight=\"%d\" />\n", model.c_str(), width, height);
+        std::fprintf(fp, "\t<fyi numOfFrames=\"%d\" aggregateVMAF=\"%s\" execFps=\"%s\" />\n", (int)F, fmt_g(aggregate).c_str(), fmt_g(exec_fps).c_str());
+        std::fprintf(fp, "\t<frames>\n");
+        for (size_t i = 0; i < F; ++i) {
+            std::fprintf(fp, "\t\t<frame frameNum=\"%d\"", (int)i);
+            for (auto &kv : result) std::fprintf(fp, " %s=\"%s\"", kv.first.c_str(), fmt_g(kv.second[i]).c_str());
+            std::fprintf(fp, " />\n");
+        }
+        std::fprintf(fp, "\t</frames>\n</VMAF>\n");
+    }
+    std::fclose(fp);
+}
+
+double run_vmaf(const char *fmt, int width, int height, int (*read_frame)(float *, float *, float *, int, void *), void *user_data,
+                const char *model_path, const char *log_path, const char *log_fmt, bool disable_clip, bool enable_transform,
+                bool do_psnr, bool do_ssim, bool do_ms_ssim, const char *pool_method)
+{
+    (void)fmt;
+    std::printf("Start calculating VMAF score...\n");             // vmaf.cpp:638
+    if (do_psnr || do_ssim || do_ms_ssim)
+        throw VmafException("psnr/ssim/ms_ssim are not features of this build (MI355X VMAF v0.6.1 hot path only)");
+    if (!model_path) throw VmafException("Error loading model (.pkl): null path");
+    if (!read_frame) throw VmafException("read_frame callback is null");
+
+    vmaf_amd::VmafModel model;
+    try { model = vmaf_amd::load_vmaf_model(model_path); }
+    catch (const std::runtime_error &e) { throw VmafException(e.what()); }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<double> atoms;
+    extract_atoms(read_frame, user_data, width, height, atoms);
+    const size_t F = atoms.size() / kAtoms;
+    if (F == 0) throw VmafException("no frames delivered by read_frame");
+    std::vector<double> vmaf;
+    std::map<std::string, std::vector<double>> result;            // std::map: keys in alphabetical order, vmaf.h:126-134
+    fuse(model, atoms, F, disable_clip, enable_transform, parse_devices()[0], vmaf, result);
+    result["vmaf"] = vmaf;
+    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    const double aggregate = pool(vmaf, pool_method);
+    const double exec_fps = (double)F / elapsed;
+    std::printf("Exec FPS: %f\n", exec_fps);                      // vmaf.cpp:664-673
+    if (pool_method) std::printf("VMAF score (%s) = %f\n", pool_method, aggregate);
+    else std::printf("VMAF score = %f\n", aggregate);
+    std::fflush(stdout);
+    if (log_path) write_logs(log_path, log_fmt, model_path, width, height, F, aggregate, exec_fps, result);
+    return aggregate;
+}
+
+void copy_err(char *errbuf, int len, const char *msg)
+{
+    if (errbuf && len > 0) { std::strncpy(errbuf, msg, (size_t)len - 1); errbuf[len - 1] = 0; }
+}
+
+}  // namespace
+
+extern "C" {
+
+double compute_vmaf(char *fmt, int width, int height, int (*read_frame)(float *, float *, float *, int, void *), void *user_data,
+                    char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform,
+                    int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method)
+{
+    (void)disable_avx;                                             // libvmaf.cpp:56-61: no CPU convolution here
+    return run_vmaf(fmt, width, height, read_frame, user_data, model_path, log_path, log_fmt, disable_clip != 0,
+                    (enable_transform || phone_model), do_psnr != 0, do_ssim != 0, do_ms_ssim != 0, pool_method);
+}
+
+int compute_vmaf_noexcept(double *score, char *fmt, int width, int height, int (*read_frame)(float *, float *, float *, int, void *),
+                          void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx,
+                          int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method,
+                          char *errbuf, int errbuf_len)
+{
+    try {
+        const double s = compute_vmaf(fmt, width, height, read_frame, user_data, model_path, log_path, log_fmt, disable_clip, disable_avx,
+                                      enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, pool_method);
+        if (score) *score = s;
+        return 0;
+    } catch (const std::exception &e) {
+        copy_err(errbuf, errbuf_len, e.what());
+        return 1;
+    } catch (...) {
+        copy_err(errbuf, errbuf_len, "unknown error");
+        return 1;
+    }
+}
+
+int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip, int enable_transform,
+                                int device, double *vmaf_out, double *features_out, char *errbuf, int errbuf_len)
+{
+    try {
+        if (!model_path || !atoms || !vmaf_out || nframes <= 0) throw VmafException("bad argument");
+        const vmaf_amd::VmafModel model = vmaf_amd::load_vmaf_model(model_path);
+        std::vector<double> a(atoms, atoms + (size_t)nframes * kAtoms), vmaf;
+        std::map<std::string, std::vector<double>> feats;
+        fuse(model, a, (size_t)nframes, disable_clip != 0, enable_transform != 0, device, vmaf, feats);
+        std::copy(vmaf.begin(), vmaf.end(), vmaf_out);
+        if (features_out) {
+            const size_t D = model.feature_names.size();
+            for (size_t j = 0; j < D; ++j) {
+                const std::vector<double> &v = feats[short_feature_name(model.feature_names[j])];
+                for (int i = 0; i < nframes; ++i) features_out[(size_t)i * D + j] = v[i];
+            }
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        copy_err(errbuf, errbuf_len, e.what());
+        return 1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// main.cpp - vmafossexec for the MI355X engine.  Same argv contract, messages and exit codes as the
+// reference CLI (wrapper/src/main.cpp:49-232), with its own file-backed read_frame callback
+// (behaviour of feature/src/common/frame.c:26-129 + file_io.c:86-172).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "../../include/libvmaf.h"
+
+namespace {
+
+struct YuvPair {
+    FILE *ref = nullptr, *dis = nullptr;
+    int width = 0, height = 0;
+    bool ten_bit = false;
+    size_t chroma_samples = 0;          // samples to skip after each luma plane (main.cpp:69-86)
+    std::vector<unsigned char> row;
+};
+
+// One luma plane -> fp32 in 8-bit units (10-bit: value / 4.0, file_io.c:159-163). 0 ok, 1 short read.
+int read_luma(FILE *f, YuvPair &s, float *dst, int stride_byte)
+{
+    const size_t bpp = s.ten_bit ? 2 : 1;
+    s.row.resize((size_t)s.width * bpp);
+    for (int i = 0; i < s.height; ++i) {
+        if (std::fread(s.row.data(), bpp, (size_t)s.width, f) != (size_t)s.width) return 1;
+        float *out = (float *)((char *)dst + (size_t)i * stride_byte);
+        if (s.ten_bit) {
+            for (int j = 0; j < s.width; ++j) {
+                const unsigned v = s.row[2 * j] | ((unsigned)s.row[2 * j + 1] << 8);   // little-endian words
+                out[j] = (float)(v / 4.0);
+            }
+        } else {
+            for (int j = 0; j < s.width; ++j) out[j] = (float)s.row[j];
+        }
+    }
+    return 0;
+}
+
+// Skip the chroma planes; seek when the stream allows it, otherwise read and discard (FIFOs).
+void skip_chroma(FILE *f, YuvPair &s, float *scratch, size_t scratch_bytes)
+{
+    size_t bytes = s.chroma_samples * (s.ten_bit ? 2 : 1);
+    if (std::fseek(f, (long)bytes, SEEK_CUR) == 0) return;
+    while (bytes) {
+        const size_t n = std::min(bytes, scratch_bytes);
+        if (std::fread(scratch, 1, n, f) != n) { std::fprintf(stderr, "fread u and v failed.\n"); return; }
+        bytes -= n;
+    }
+}
+
+// libvmaf read_frame contract: 0 frame delivered, 2 end of stream, 1 failure (frame.c:48-78)
+int read_frame_cb(float *ref_data, float *dis_data, float *temp_data, int stride_byte, void *user)
+{
+    YuvPair &s = *(YuvPair *)user;
+    if (read_luma(s.ref, s, ref_data, stride_byte)) return std::feof(s.ref) ? 2 : 1;
+    if (read_luma(s.dis, s, dis_data, stride_byte)) return std::feof(s.dis) ? 2 : 1;
+    const size_t scratch = (size_t)stride_byte * s.height * 2;
+    skip_chroma(s.ref, s, temp_data, scratch);
+    skip_chroma(s.dis, s, temp_data, scratch);
+    return 0;
+}
+
+const char *opt_value(char **b, char **e, const std::string &name)
+{
+    char **it = std::find(b, e, name);
+    return (it != e && ++it != e) ? *it : nullptr;
+}
+bool opt_present(char **b, char **e, const std::string &name) { return std::find(b, e, name) != e; }
+
+void usage(const char *prog)
+{
+    std::fprintf(stderr, "Usage: %s fmt width height ref_path dis_path model_path [--log log_path] [--log-fmt log_fmt] [--disable-clip] "
+                         "[--disable-avx] [--psnr] [--ssim] [--ms-ssim] [--phone-model]\n", prog);
+    std::fprintf(stderr, "fmt:\n\tyuv420p\n\tyuv422p\n\tyuv444p\n\tyuv420p10le\n\tyuv422p10le\n\tyuv444p10le\n\n");
+    std::fprintf(stderr, "log_fmt:\n\txml (default)\n\tjson\n\n");
+}
+
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+    if (argc < 7) { usage(argv[0]); return -1; }
+    char *fmt = argv[1];
+    int width = 0, height = 0;
+    try { width = std::stoi(argv[2]); height = std::stoi(argv[3]); }
+    catch (const std::exception &e) { std::fprintf(stderr, "Error: %s\n", e.what()); usage(argv[0]); return -1; }
+    char *ref_path = argv[4], *dis_path = argv[5], *model_path = argv[6];
+    if (width <= 0 || height <= 0) {
+        std::fprintf(stderr, "Error: Invalid frame resolution %d x %d\n", width, height);
+        usage(argv[0]);
+        return -1;
+    }
+    char **ob = argv + 7, **oe = argv + argc;
+    const char *log_path = opt_value(ob, oe, "--log");
+    const char *log_fmt = opt_value(ob, oe, "--log-fmt");
+    if (log_fmt && std::strcmp(log_fmt, "xml") && std::strcmp(log_fmt, "json")) {
+        std::fprintf(stderr, "Error: log_fmt must be xml or json, but is %s\n", log_fmt);
+        return -1;
+    }
+    const bool disable_clip = opt_present(ob, oe, "--disable-clip"), disable_avx = opt_present(ob, oe, "--disable-avx");
+    const bool enable_transform = opt_present(ob, oe, "--enable-transform"), phone_model = opt_present(ob, oe, "--phone-model");
+    const bool do_psnr = opt_present(ob, oe, "--psnr"), do_ssim = opt_present(ob, oe, "--ssim"), do_ms_ssim = opt_present(ob, oe, "--ms-ssim");
+    const char *pool_method = opt_value(ob, oe, "--pool");
+    if (pool_method && std::strcmp(pool_method, "min") && std::strcmp(pool_method, "harmonic_mean") && std::strcmp(pool_method, "mean")) {
+        std::fprintf(stderr, "Error: pool_method must be min, harmonic_mean or mean, but is %s\n", pool_method);
+        return -1;
+    }
+
+    YuvPair s;
+    s.width = width; s.height = height;
+    const std::string f = fmt;
+    const size_t n = (size_t)width * height;
+    if (f == "yuv420p" || f == "yuv420p10le") {
+        if (n % 2 != 0) { std::fprintf(stderr, "(width * height) %% 2 != 0, width = %d, height = %d.\n", width, height); return 1; }
+        s.chroma_samples = n / 2;
+    } else if (f == "yuv422p" || f == "yuv422p10le") s.chroma_samples = n;
+    else if (f == "yuv444p" || f == "yuv444p10le") s.chroma_samples = n * 2;
+    else { std::fprintf(stderr, "unknown format %s.\n", fmt); return 1; }
+    s.ten_bit = f.size() > 4 && f.compare(f.size() - 4, 4, "10le") == 0;
+
+    int ret = 0;
+    if (!(s.ref = std::fopen(ref_path, "rb"))) { std::fprintf(stderr, "fopen ref_path %s failed.\n", ref_path); ret = 1; }
+    else if (!(s.dis = std::fopen(dis_path, "rb"))) { std::fprintf(stderr, "fopen ref_path %s failed.\n", dis_path); ret = 1; }
+    if (!ret) {
+        try {
+            compute_vmaf(fmt, width, height, read_frame_cb, &s, model_path, (char *)log_path, (char *)log_fmt, disable_clip, disable_avx,
+                         enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "Error: %s\n", e.what());
+            usage(argv[0]);
+            ret = -1;
+        }
+    }
+    if (s.ref) std::fclose(s.ref);
+    if (s.dis) std::fclose(s.dis);
+    return ret;
+}

@@ -1,0 +1,432 @@
+// vmaf_engine.cpp - the vmaf_hip_* C-ABI (include/vmaf_hip.h): device memory, streams, launch order
+// and the host-side finishing of the raw device sums into the 20 reference atoms.
+//
+// HBM layout per engine (B = max_batch frames, all fp32, dense rows):
+//   vif pyramid  scale 1..3: ref + dis planes, (w>>s) x (h>>s) each, B of them      (vif.c:157-186)
+//   adm LL bands level 0..2: ref + dis planes, ceil-halved sizes, B of them         (adm.c:241-247)
+//   carry[2]     blurred ref of the last frame of the previous call, w x h          (combo.c:326)
+//   staging      B un-offset ref + dis planes for the host-pointer entry point
+//   partials     per-block fp64 partial sums of every kernel of the batch
+//   sums         B x VK_NSUMS fp64, copied to pinned host memory
+// The VIF chain, the ADM chain and motion run on three streams and join before the reduction.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/vmaf_hip.h"
+#include "vmaf_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(_e));      \
+    } while (0)
+
+// adm_tools.h:105-115 (Watson DWT quantisation step, luma, 7/9 basis amplitudes) -> 1/Q as adm_csf uses it
+float adm_rfactor(int lambda, int theta)
+{
+    static const float a = 0.495f, k = 0.466f, f0 = 0.401f;
+    static const float g[4] = { 1.501f, 1.0f, 0.534f, 1.0f };
+    static const float amp[6][4] = {
+        { 0.62171f, 0.67234f, 0.72709f, 0.67234f }, { 0.34537f, 0.41317f, 0.49428f, 0.41317f },
+        { 0.18004f, 0.22727f, 0.28688f, 0.22727f }, { 0.091401f, 0.11792f, 0.15214f, 0.11792f },
+        { 0.045943f, 0.059758f, 0.077727f, 0.059758f }, { 0.023013f, 0.030018f, 0.039156f, 0.030018f } };
+    const float r = (float)(3.0f * 1080 * 3.14159265358979323846264338327 / 180.0);
+    const float t = (float)std::log10(std::pow(2.0, lambda + 1) * f0 * g[theta] / r);
+    const float q = (float)(2.0 * a * std::pow(10.0, k * t * t) / amp[lambda][theta]);
+    return 1.0f / q;
+}
+
+}  // namespace
+
+struct vmaf_hip_engine {
+    int device = 0, w = 0, h = 0, max_batch = 0;
+    hipStream_t s_main = nullptr, s_adm = nullptr, s_mot = nullptr;
+    hipEvent_t ev_in = nullptr, ev_adm = nullptr, ev_mot = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    bool timed = false;
+
+    int vw[4], vh[4];              // VIF plane size per scale
+    int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
+    float *vif_ref[4] = {}, *vif_dis[4] = {};   // [1..3]
+    float *adm_ref[4] = {}, *adm_dis[4] = {};   // [1..3] = LL of level 0..2
+    float *carry[2] = {};
+    int carry_cur = 0;
+    bool carry_valid = false;
+    float *stage_ref = nullptr, *stage_dis = nullptr;
+    double *partials = nullptr, *sums_dev = nullptr, *sums_host = nullptr;
+    size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
+    int tiles_vif[4], tiles_adm[4], tiles_mot;
+    float rfac[8];
+    int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
+
+    // pending async call
+    int pend_frames = 0;
+    bool pend_first_has_motion = false;
+    double *pend_out = nullptr;
+};
+
+namespace {
+
+// Finish one frame: VK_NSUMS raw fp64 sums -> 20 atoms, in the reference's own precision steps.
+void finish_atoms(const vmaf_hip_engine *e, const double *s, bool has_motion, double *atoms)
+{
+    // vif.c:265-291: vif_sum returns float; per-scale values widen to double, totals add in double
+    double vnum = 0, vden = 0;
+    for (int sc = 0; sc < 4; ++sc) {
+        const double n = (double)(float)s[2 * sc], d = (double)(float)s[2 * sc + 1];
+        atoms[11 + 2 * sc] = n;
+        atoms[12 + 2 * sc] = d;
+        vnum += n;
+        vden += d;
+    }
+    atoms[19] = (vden == 0.0) ? 1.0 : vnum / vden;
+
+    // adm_tools.c:76 + adm.c:229-268
+    double num = 0, den = 0;
+    for (int sc = 0; sc < 4; ++sc) {
+        const int *wn = e->win[sc];
+        const float area = powf((wn[3] - wn[1]) * (wn[2] - wn[0]) / 32.0f, 1.0f / 3.0f);
+        float num_s = 0.0f, den_s = 0.0f;
+        for (int b = 0; b < 3; ++b) num_s += powf((float)s[8 + 6 * sc + b], 1.0f / 3.0f) + area;
+        for (int b = 0; b < 3; ++b) den_s += powf((float)s[8 + 6 * sc + 3 + b], 1.0f / 3.0f) + area;
+        num += num_s;
+        den += den_s;
+        atoms[2 + 2 * sc] = num_s;
+        atoms[3 + 2 * sc] = den_s;
+    }
+    const double limit = 1e-10 * (e->w * e->h) / (1920.0 * 1080.0);
+    atoms[0] = num < limit ? 0 : num;
+    atoms[1] = den < limit ? 0 : den;
+
+    // motion.c:59: float sum / (w*h) in float
+    atoms[10] = has_motion ? (double)(float)((float)s[32] / (e->w * e->h)) : 0.0;
+}
+
+int alloc_planes(float **p, size_t floats) { HIP_TRY(hipMalloc((void **)p, floats * sizeof(float))); return 0; }
+
+int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
+                  size_t frame_stride_bytes, int nframes, int continue_sequence)
+{
+    if (row_stride_bytes % 4 || frame_stride_bytes % 4) return fail("strides must be multiples of 4 bytes");
+    if (row_stride_bytes < (size_t)e->w * 4) return fail("row stride %zu smaller than a row", row_stride_bytes);
+    if (nframes > 1 && frame_stride_bytes < row_stride_bytes * e->h) return fail("frame stride smaller than a frame");
+    const int rs = (int)(row_stride_bytes / 4);
+    const size_t fs = frame_stride_bytes / 4;
+    const bool has_carry = continue_sequence && e->carry_valid;
+    if (continue_sequence && !e->carry_valid) return fail("continue_sequence set but the engine holds no previous frame");
+
+    if (e->timed) HIP_TRY(hipEventRecord(e->ev_t0, e->s_main));
+    HIP_TRY(hipEventRecord(e->ev_in, e->s_main));             // inputs (staging copies) are ready at this point
+    HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
+    HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
+
+    // ---- VIF chain (vif.c:130-275) on s_main
+    const float *cr = d_ref, *cd = d_dis;
+    size_t cfs = fs;
+    int crs = rs;
+    for (int sc = 0; sc < 4; ++sc) {
+        if (sc > 0) {
+            const size_t ofs = (size_t)e->vw[sc] * e->vh[sc];
+            HIP_TRY(vk_launch_vif_down(sc, cr, cd, cfs, crs, e->vw[sc - 1], e->vh[sc - 1], e->vif_ref[sc], e->vif_dis[sc], ofs,
+                                       e->vw[sc], nframes, e->s_main));
+            cr = e->vif_ref[sc]; cd = e->vif_dis[sc]; cfs = ofs; crs = e->vw[sc];
+        }
+        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0, e->s_main));
+        HIP_TRY(vk_launch_vif_stat(sc, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc], e->s_main));
+        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1, e->s_main));
+    }
+
+    // ---- ADM chain (adm.c:125-254) on s_adm
+    cr = d_ref; cd = d_dis; cfs = fs; crs = rs;
+    for (int sc = 0; sc < 4; ++sc) {
+        const int bw = e->aw[sc + 1], bh = e->ah[sc + 1];
+        const size_t lfs = (size_t)bw * bh;
+        float *lr = sc < 3 ? e->adm_ref[sc + 1] : nullptr, *ld = sc < 3 ? e->adm_dis[sc + 1] : nullptr;
+        HIP_TRY(vk_launch_adm_scale(sc, cr, cd, cfs, crs, e->aw[sc], e->ah[sc], lr, ld, lfs, bw, e->rfac[2 * sc], e->rfac[2 * sc + 1],
+                                    e->win[sc][0], e->win[sc][1], e->win[sc][2], e->win[sc][3], nframes,
+                                    e->partials + e->part_off_adm[sc], e->s_adm));
+        cr = lr; cd = ld; cfs = lfs; crs = bw;
+    }
+    HIP_TRY(hipEventRecord(e->ev_adm, e->s_adm));
+
+    // ---- motion (combo.c:309-326) on s_mot
+    HIP_TRY(vk_launch_motion(d_ref, fs, rs, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
+                             e->partials + e->part_off_mot, e->s_mot));
+    HIP_TRY(hipEventRecord(e->ev_mot, e->s_mot));
+    e->carry_cur = 1 - e->carry_cur;
+    e->carry_valid = true;
+
+    // ---- join, reduce, copy back
+    HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_adm, 0));
+    HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_mot, 0));
+    vk_reduce_table tab;
+    int q = 0;
+    for (int sc = 0; sc < 4; ++sc)
+        for (int c = 0; c < 2; ++c) tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c };
+    for (int sc = 0; sc < 4; ++sc)
+        for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c };
+    tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0 };
+    HIP_TRY(vk_launch_reduce(e->partials, &tab, nframes, e->sums_dev, e->s_main));
+    HIP_TRY(hipMemcpyAsync(e->sums_host, e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
+    if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1, e->s_main));
+    return 0;
+}
+
+int check_call(vmaf_hip_engine *e, const void *a, const void *b, int nframes, const double *out)
+{
+    if (!e) return fail("null engine");
+    if (!a || !b || !out) return fail("null pointer argument");
+    if (nframes <= 0 || nframes > e->max_batch) return fail("nframes %d outside 1..%d", nframes, e->max_batch);
+    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    HIP_TRY(hipSetDevice(e->device));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vmaf_hip_last_error(void) { return g_err; }
+
+int vmaf_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int height, int max_batch)
+{
+    if (!out) return fail("null out pointer");
+    *out = nullptr;
+    // below 17 the mirrored taps of the coarsest ADM/VIF scales leave the plane (undefined in the reference too)
+    if (width < 32 || height < 32) return fail("frame %dx%d too small (minimum 32x32)", width, height);
+    if (width > 16384 || height > 16384) return fail("frame %dx%d too large", width, height);
+    if (max_batch < 1 || max_batch > 4096) return fail("max_batch %d outside 1..4096", max_batch);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail("device %d outside 0..%d", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+
+    vmaf_hip_engine *e = new (std::nothrow) vmaf_hip_engine();
+    if (!e) return fail("out of host memory");
+    e->device = device; e->w = width; e->h = height; e->max_batch = max_batch;
+    const size_t B = (size_t)max_batch;
+
+    e->vw[0] = width; e->vh[0] = height;
+    for (int s = 1; s < 4; ++s) { e->vw[s] = e->vw[s - 1] / 2; e->vh[s] = e->vh[s - 1] / 2; }      // vif.c:172-173
+    e->aw[0] = width; e->ah[0] = height;
+    for (int s = 1; s < 5; ++s) { e->aw[s] = (e->aw[s - 1] + 1) / 2; e->ah[s] = (e->ah[s - 1] + 1) / 2; }  // adm.c:135-136
+    for (int s = 0; s < 4; ++s) {
+        e->rfac[2 * s] = adm_rfactor(s, 1);
+        e->rfac[2 * s + 1] = adm_rfactor(s, 2);
+        const int bw = e->aw[s + 1], bh = e->ah[s + 1];
+        const int left = (int)(bw * 0.1 - 0.5), top = (int)(bh * 0.1 - 0.5);                  // adm_tools.c:54-57
+        e->win[s][0] = left; e->win[s][1] = top; e->win[s][2] = bw - left; e->win[s][3] = bh - top;
+    }
+
+    int rc = 0;
+    auto cleanup = [&]() { vmaf_hip_engine_destroy(e); return 1; };
+    if (hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_adm, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_mot, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
+    hipEvent_t *evs[] = { &e->ev_in, &e->ev_adm, &e->ev_mot };
+    for (auto ev : evs)
+        if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
+    hipEvent_t *tevs[] = { &e->ev_t0, &e->ev_t1, &e->ev_k0, &e->ev_k1 };
+    for (auto ev : tevs)
+        if (hipEventCreate(ev) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
+
+    for (int s = 1; s < 4 && !rc; ++s) {
+        rc |= alloc_planes(&e->vif_ref[s], B * e->vw[s] * e->vh[s]);
+        rc |= alloc_planes(&e->vif_dis[s], B * e->vw[s] * e->vh[s]);
+        rc |= alloc_planes(&e->adm_ref[s], B * e->aw[s] * e->ah[s]);
+        rc |= alloc_planes(&e->adm_dis[s], B * e->aw[s] * e->ah[s]);
+    }
+    for (int i = 0; i < 2 && !rc; ++i) rc |= alloc_planes(&e->carry[i], (size_t)width * height);
+    if (!rc) rc |= alloc_planes(&e->stage_ref, B * width * height);
+    if (!rc) rc |= alloc_planes(&e->stage_dis, B * width * height);
+
+    size_t off = 0;
+    for (int s = 0; s < 4; ++s) { e->tiles_vif[s] = vk_vif_tiles(e->vw[s], e->vh[s]); e->part_off_vif[s] = off; off += B * e->tiles_vif[s] * 2; }
+    for (int s = 0; s < 4; ++s) { e->tiles_adm[s] = vk_adm_tiles(e->aw[s], e->ah[s]); e->part_off_adm[s] = off; off += B * e->tiles_adm[s] * 6; }
+    e->tiles_mot = vk_motion_tiles(width, height); e->part_off_mot = off; off += B * e->tiles_mot;
+    e->part_total = off;
+    if (!rc && hipMalloc((void **)&e->partials, off * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(partials) failed");
+    if (!rc && hipMalloc((void **)&e->sums_dev, B * VK_NSUMS * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(sums) failed");
+    if (!rc && hipHostMalloc((void **)&e->sums_host, B * VK_NSUMS * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail("hipHostMalloc failed");
+    if (rc) return cleanup();
+    *out = e;
+    return 0;
+}
+
+void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (int s = 0; s < 4; ++s) {
+        (void)hipFree(e->vif_ref[s]); (void)hipFree(e->vif_dis[s]);
+        (void)hipFree(e->adm_ref[s]); (void)hipFree(e->adm_dis[s]);
+    }
+    (void)hipFree(e->carry[0]); (void)hipFree(e->carry[1]);
+    (void)hipFree(e->stage_ref); (void)hipFree(e->stage_dis);
+    (void)hipFree(e->partials); (void)hipFree(e->sums_dev);
+    if (e->sums_host) (void)hipHostFree(e->sums_host);
+    hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_t0, e->ev_t1, e->ev_k0, e->ev_k1 };
+    for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
+    hipStream_t ss[] = { e->s_main, e->s_adm, e->s_mot };
+    for (auto s : ss) if (s) (void)hipStreamDestroy(s);
+    delete e;
+}
+
+int vmaf_hip_engine_sync(vmaf_hip_engine *e)
+{
+    if (!e) return fail("null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->s_main));
+    for (int f = 0; f < e->pend_frames; ++f)
+        finish_atoms(e, e->sums_host + (size_t)f * VK_NSUMS, f > 0 || e->pend_first_has_motion,
+                     e->pend_out + (size_t)f * VMAF_HIP_ATOMS);
+    e->pend_frames = 0;
+    return 0;
+}
+
+int vmaf_hip_extract_device_async(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
+                                  size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
+{
+    if (check_call(e, d_ref, d_dis, nframes, atoms_out)) return 1;
+    if (enqueue_batch(e, d_ref, d_dis, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence)) return 1;
+    e->pend_frames = nframes;
+    e->pend_first_has_motion = continue_sequence != 0;
+    e->pend_out = atoms_out;
+    return 0;
+}
+
+int vmaf_hip_extract_device(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
+                            size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
+{
+    if (vmaf_hip_extract_device_async(e, d_ref, d_dis, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence, atoms_out))
+        return 1;
+    return vmaf_hip_engine_sync(e);
+}
+
+int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const float *h_dis, size_t row_stride_bytes,
+                          size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
+{
+    if (check_call(e, h_ref, h_dis, nframes, atoms_out)) return 1;
+    if (row_stride_bytes < (size_t)e->w * 4) return fail("row stride %zu smaller than a row", row_stride_bytes);
+    // stage densely (row stride = w floats) so the kernels see one geometry
+    const size_t dense_row = (size_t)e->w * 4, dense_frame = dense_row * e->h;
+    for (int f = 0; f < nframes; ++f) {
+        const char *sr = (const char *)h_ref + (size_t)f * frame_stride_bytes, *sd = (const char *)h_dis + (size_t)f * frame_stride_bytes;
+        HIP_TRY(hipMemcpy2DAsync((char *)e->stage_ref + f * dense_frame, dense_row, sr, row_stride_bytes, dense_row, e->h,
+                                 hipMemcpyHostToDevice, e->s_main));
+        HIP_TRY(hipMemcpy2DAsync((char *)e->stage_dis + f * dense_frame, dense_row, sd, row_stride_bytes, dense_row, e->h,
+                                 hipMemcpyHostToDevice, e->s_main));
+    }
+    if (enqueue_batch(e, e->stage_ref, e->stage_dis, dense_row, dense_frame, nframes, continue_sequence)) return 1;
+    e->pend_frames = nframes;
+    e->pend_first_has_motion = continue_sequence != 0;
+    e->pend_out = atoms_out;
+    return 0;
+}
+
+int vmaf_hip_extract_host(vmaf_hip_engine *e, const float *h_ref, const float *h_dis, size_t row_stride_bytes,
+                          size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
+{
+    if (vmaf_hip_extract_host_async(e, h_ref, h_dis, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence, atoms_out))
+        return 1;
+    return vmaf_hip_engine_sync(e);
+}
+
+void *vmaf_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { fail("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+
+void vmaf_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t row_stride_bytes)
+{
+    if (!e || !d_ref) return fail("null argument");
+    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (row_stride_bytes % 4 || row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
+    HIP_TRY(hipSetDevice(e->device));
+    // one-frame motion launch without predecessor: only its carry_out side effect is used
+    HIP_TRY(vk_launch_motion(d_ref, 0, (int)(row_stride_bytes / 4), e->w, e->h, 1, 0, e->carry[e->carry_cur],
+                             e->carry[1 - e->carry_cur], e->partials + e->part_off_mot, e->s_main));
+    e->carry_cur = 1 - e->carry_cur;
+    e->carry_valid = true;
+    HIP_TRY(hipStreamSynchronize(e->s_main));
+    return 0;
+}
+
+int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row_stride_bytes)
+{
+    if (!e || !h_ref) return fail("null argument");
+    if (row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t dense_row = (size_t)e->w * 4;
+    HIP_TRY(hipMemcpy2DAsync(e->stage_ref, dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+    return vmaf_hip_motion_seed_device(e, e->stage_ref, dense_row);
+}
+
+int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho,
+                         const double *x, int n, double *out)
+{
+    if (!sv || !coef || !x || !out) return fail("null pointer argument");
+    if (n_sv <= 0 || dim <= 0 || n < 0) return fail("bad sizes n_sv=%d dim=%d n=%d", n_sv, dim, n);
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail("device %d outside 0..%d", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    double *d_sv = nullptr, *d_coef = nullptr, *d_x = nullptr, *d_out = nullptr;
+    int rc = 0;
+    hipError_t err;
+#define SVM_TRY(expr) do { if (!rc && (err = (expr)) != hipSuccess) rc = fail("%s failed: %s", #expr, hipGetErrorString(err)); } while (0)
+    SVM_TRY(hipMalloc((void **)&d_sv, sizeof(double) * n_sv * dim));
+    SVM_TRY(hipMalloc((void **)&d_coef, sizeof(double) * n_sv));
+    SVM_TRY(hipMalloc((void **)&d_x, sizeof(double) * (size_t)n * dim));
+    SVM_TRY(hipMalloc((void **)&d_out, sizeof(double) * n));
+    SVM_TRY(hipMemcpy(d_sv, sv, sizeof(double) * n_sv * dim, hipMemcpyHostToDevice));
+    SVM_TRY(hipMemcpy(d_coef, coef, sizeof(double) * n_sv, hipMemcpyHostToDevice));
+    SVM_TRY(hipMemcpy(d_x, x, sizeof(double) * (size_t)n * dim, hipMemcpyHostToDevice));
+    SVM_TRY(vk_launch_svm(d_sv, d_coef, n_sv, dim, gamma, rho, d_x, n, d_out, nullptr));
+    SVM_TRY(hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+#undef SVM_TRY
+    (void)hipFree(d_sv); (void)hipFree(d_coef); (void)hipFree(d_x); (void)hipFree(d_out);
+    return rc;
+}
+
+double vmaf_hip_last_kernel_ms(vmaf_hip_engine *e, int which)
+{
+    if (!e) return -1.0;
+    if (!e->timed) { e->timed = true; return -1.0; }          // first call arms the events for the next batch
+    float ms = -1.0f;
+    hipError_t err = which == 1 ? hipEventElapsedTime(&ms, e->ev_k0, e->ev_k1) : hipEventElapsedTime(&ms, e->ev_t0, e->ev_t1);
+    return err == hipSuccess ? (double)ms : -1.0;
+}
+
+}  // extern "C"

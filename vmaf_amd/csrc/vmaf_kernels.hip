@@ -1,0 +1,635 @@
+// vmaf_kernels.hip - hand-written gfx950 (MI355X / CDNA4) kernels for the VMAF v0.6.1 feature path.
+//
+// Numerics policy: every multiply and add in the stencils rounds separately (build with
+// -ffp-contract=off) and filter taps are accumulated left to right, i.e. the arithmetic of the
+// reference's scalar path (feature/src/vif_tools.c:292-328, common/convolution.c:26-76,
+// adm_tools.c:308-389).  Per-pixel values are therefore bit-identical to the reference run with
+// disable_avx; only the final plane sums differ (fp64 tree here, fp32 row-then-total there).
+//
+// Kernels (one launch covers a whole batch of frames: blockIdx.z = frame):
+//   vif_stat_kernel<FW>   fused: tile+halo of ref/dis -> LDS, vertical pass of {r,d,r^2,d^2,rd},
+//                         horizontal pass, per-pixel VIF statistic, block-reduced num/den
+//   vif_down_kernel<FW>   blur with the next scale's filter evaluated at even samples only
+//   adm_scale_kernel      fused: db2 DWT (ref+dis) in LDS, decouple, CSF, 3x3 masking threshold,
+//                         masked cube sums over the centre window, LL bands to HBM
+//   motion_kernel         5-tap blur of frame f and f-1 (or carried blurred plane), SAD
+//   reduce_kernel         deterministic fp64 reduction of the per-block partials
+//   svm_rbf_kernel        batched nu-SVR RBF prediction
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vmaf_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------- tables
+// feature/src/vif_tools.c:82-87
+__device__ constexpr float kVif17[17] = { 0.00745626912f, 0.0142655009f, 0.0250313189f, 0.0402820669f,
+    0.0594526194f, 0.0804751068f, 0.0999041125f, 0.113746084f, 0.118773937f, 0.113746084f, 0.0999041125f,
+    0.0804751068f, 0.0594526194f, 0.0402820669f, 0.0250313189f, 0.0142655009f, 0.00745626912f };
+__device__ constexpr float kVif9[9] = { 0.0189780835f, 0.0558981746f, 0.120920904f, 0.192116052f, 0.224173605f,
+    0.192116052f, 0.120920904f, 0.0558981746f, 0.0189780835f };
+__device__ constexpr float kVif5[5] = { 0.054488685f, 0.244201347f, 0.402619958f, 0.244201347f, 0.054488685f };
+__device__ constexpr float kVif3[3] = { 0.166378498f, 0.667243004f, 0.166378498f };
+// feature/src/motion_tools.h:24-29
+__device__ constexpr float kMotion5[5] = { 0.054488685f, 0.244201342f, 0.402619947f, 0.244201342f, 0.054488685f };
+// feature/src/adm_tools.c:48-49
+__device__ constexpr float kDb2Lo[4] = { 0.482962913144690f, 0.836516303737469f, 0.224143868041857f, -0.129409522550921f };
+__device__ constexpr float kDb2Hi[4] = { -0.129409522550921f, -0.224143868041857f, 0.836516303737469f, -0.482962913144690f };
+
+template <int FW> __device__ __forceinline__ constexpr float vif_tap(int k)
+{
+    return FW == 17 ? kVif17[k] : FW == 9 ? kVif9[k] : FW == 5 ? kVif5[k] : kVif3[k];
+}
+
+// Mirror rule of every stencil on the path (vif_tools.c:301, adm_tools.c:241-248); the final
+// clamp only matters for tiles hanging over the image, whose results are masked out.
+__device__ __forceinline__ int mirror_idx(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - i - 1 : i;
+    return min(max(i, 0), n - 1);
+}
+
+// ---------------------------------------------------------------- block reduction (deterministic)
+template <int K, int NWAVES>
+__device__ __forceinline__ void block_reduce_store(double (&v)[K], double *red /* NWAVES*K doubles of LDS */, double *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave * K + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double s = 0;
+#pragma unroll
+        for (int wv = 0; wv < NWAVES; ++wv) s += red[wv * K + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------- VIF statistic
+// feature/src/vif_tools.c:33-75
+__device__ __forceinline__ float log2f_approx(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    const float mant = __uint_as_float((u & 0x007FFFFFu) | 0x3F800000u);
+    const float e = (float)((int)((u & 0x7F800000u) >> 23) - 127);
+    const float t = mant - 1.0f;
+    float v = 0.0f;
+    v = v * t + -0.012671635276421f;
+    v = v * t + 0.064841182402670f;
+    v = v * t + -0.157048836463065f;
+    v = v * t + 0.257167726303123f;
+    v = v * t + -0.353800560300520f;
+    v = v * t + 0.480131410397451f;
+    v = v * t + -0.721314327952201f;
+    v = v * t + 1.442694803896991f;
+    v = v * t + 0.0f;
+    float r = e + v;
+    r = (x == 0.0f) ? -INFINITY : r;
+    r = (x < 0.0f) ? __uint_as_float(0x7FC00000u) : r;
+    return r;
+}
+
+// feature/src/vif_tools.c:243-263
+__device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float yyf, float xyf, float &num, float &den)
+{
+    const float sigma_nsq = 2.0f;
+    const float sigma_max_inv = (float)(4.0 / (255.0 * 255.0));
+    const float m1sq = mu1 * mu1, m2sq = mu2 * mu2, m12 = mu1 * mu2;
+    const float s1 = xxf - m1sq;
+    const float s2 = yyf - m2sq;
+    const float s12 = xyf - m12;
+    if (s1 < sigma_nsq) {
+        const float p = s2 * sigma_max_inv;
+        num = (float)(1.0 - (double)p);
+        den = 1.0f;
+    } else {
+        const float sv = (s2 + sigma_nsq) * s1;
+        const float g = sv - s12 * s12;
+        const float l = log2f_approx(sv / g);
+        num = (s12 < 0.0f) ? 0.0f : l;
+        den = log2f_approx(1.0f + s1 / sigma_nsq);
+    }
+}
+
+constexpr int VIF_TW = 64, VIF_TH = 32, VIF_THREADS = 320, VIF_SV = 8, VIF_SH = 8;
+
+template <int FW> struct VifGeom {
+    static constexpr int R = FW / 2;
+    static constexpr int IW = VIF_TW + 2 * R;                 // tile + halo, columns
+    static constexpr int IH = VIF_TH + 2 * R;                 // tile + halo, rows
+    static constexpr int VS = (IW + 3) / 4 * 4 + ((((IW + 3) / 4) & 1) ? 0 : 4);   // 4*odd >= IW: conflict-free b128 rows
+    static constexpr int NV = VIF_SH + 2 * R;                 // values one horizontal strip needs
+    static constexpr int NV4 = (NV + 3) / 4;
+    static constexpr int IN_FLOATS = 2 * IH * IW;
+    static constexpr int V_FLOATS = 5 * VIF_TH * VS;
+    static constexpr int SMEM_FLOATS = (IN_FLOATS > V_FLOATS ? IN_FLOATS : V_FLOATS);
+    static_assert(IW * (VIF_TH / VIF_SV) <= VIF_THREADS, "one vertical item per thread");
+    static_assert((VIF_TW / VIF_SH - 1) * VIF_SH + 4 * NV4 <= VS, "horizontal reads stay inside a row");
+};
+
+// Sequential-tap 1-D filter over a register window: out[o] = sum_k f[k] * v[o + k]
+template <int FW, int NOUT>
+__device__ __forceinline__ void taps_window(const float *v, float *out)
+{
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * v[o + k];
+        out[o] = acc;
+    }
+}
+
+// Fused VIF scale kernel. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products,
+// three filtered moments, vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.
+template <int FW, bool OFFSET>
+__global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                               size_t frame_stride, int row_stride, int w, int h,
+                                                               double *__restrict__ partial)
+{
+    using G = VifGeom<FW>;
+    constexpr int R = G::R, IW = G::IW, IH = G::IH, VS = G::VS;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS + 16];
+    float *in_r = smem, *in_d = smem + IH * IW;
+    double *red = reinterpret_cast<double *>(smem);           // reused after the last LDS read
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * VIF_TW, y0 = blockIdx.y * VIF_TH;
+    const float *fr = ref + (size_t)blockIdx.z * frame_stride;
+    const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+
+    // ---- stage tile + halo (mirrored at the image border) into LDS
+    for (int idx = tid; idx < IH * IW; idx += VIF_THREADS) {
+        const int ly = idx / IW, lx = idx - ly * IW;
+        const int gy = mirror_idx(y0 - R + ly, h), gx = mirror_idx(x0 - R + lx, w);
+        const size_t g = (size_t)gy * row_stride + gx;
+        float a = fr[g], b = fd[g];
+        if (OFFSET) { a = a + -128.0f; b = b + -128.0f; }    // offset_image, combo.c:236-237
+        in_r[idx] = a;
+        in_d[idx] = b;
+    }
+    __syncthreads();
+
+    // ---- vertical pass: one column, VIF_SV output rows, five quantities, all in registers
+    float vo[5][VIF_SV];
+    const int vc = tid % IW, vs = tid / IW;
+    const bool vactive = tid < IW * (VIF_TH / VIF_SV);
+    if (vactive) {
+        float rv[VIF_SV + 2 * R], dv[VIF_SV + 2 * R], t[VIF_SV + 2 * R];
+#pragma unroll
+        for (int i = 0; i < VIF_SV + 2 * R; ++i) {
+            rv[i] = in_r[(vs * VIF_SV + i) * IW + vc];
+            dv[i] = in_d[(vs * VIF_SV + i) * IW + vc];
+        }
+        taps_window<FW, VIF_SV>(rv, vo[0]);
+        taps_window<FW, VIF_SV>(dv, vo[1]);
+#pragma unroll
+        for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * rv[i];
+        taps_window<FW, VIF_SV>(t, vo[2]);
+#pragma unroll
+        for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = dv[i] * dv[i];
+        taps_window<FW, VIF_SV>(t, vo[3]);
+#pragma unroll
+        for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * dv[i];
+        taps_window<FW, VIF_SV>(t, vo[4]);
+    }
+    __syncthreads();                                          // input tile fully consumed: alias it
+    float *vout = smem;
+    if (vactive) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int o = 0; o < VIF_SV; ++o) vout[(q * VIF_TH + vs * VIF_SV + o) * VS + vc] = vo[q][o];
+    }
+    __syncthreads();
+
+    // ---- horizontal pass + statistic: one row, VIF_SH output columns
+    double acc[2] = { 0.0, 0.0 };
+    if (tid < VIF_TH * (VIF_TW / VIF_SH)) {
+        const int row = tid % VIF_TH, strip = tid / VIF_TH;
+        float ho[5][VIF_SH];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float v[4 * G::NV4];
+            const float4 *p = reinterpret_cast<const float4 *>(vout + (q * VIF_TH + row) * VS + strip * VIF_SH);
+#pragma unroll
+            for (int m = 0; m < G::NV4; ++m) {
+                const float4 f4 = p[m];
+                v[4 * m] = f4.x; v[4 * m + 1] = f4.y; v[4 * m + 2] = f4.z; v[4 * m + 3] = f4.w;
+            }
+            taps_window<FW, VIF_SH>(v, ho[q]);
+        }
+        const int gy = y0 + row;
+#pragma unroll
+        for (int o = 0; o < VIF_SH; ++o) {
+            const int gx = x0 + strip * VIF_SH + o;
+            float n, d;
+            vif_pixel(ho[0][o], ho[1][o], ho[2][o], ho[3][o], ho[4][o], n, d);
+            if (gx < w && gy < h) { acc[0] += (double)n; acc[1] += (double)d; }
+        }
+    }
+    __syncthreads();                                          // vout fully consumed: alias for the reduction
+    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
+}
+
+// ---------------------------------------------------------------- VIF pyramid step
+constexpr int DN_TW = 32, DN_TH = 16, DN_THREADS = 256;
+
+// vif.c:157-186: next = dec2(blur_{filter[scale+1]}(cur)); only the even samples are evaluated.
+template <int FW, bool OFFSET>
+__global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                              size_t in_frame_stride, int in_row_stride, int w, int h,
+                                                              float *__restrict__ oref, float *__restrict__ odis,
+                                                              size_t out_frame_stride, int out_row_stride, int ow, int oh)
+{
+    constexpr int R = FW / 2;
+    constexpr int IW = 2 * DN_TW + 2 * R, IH = 2 * DN_TH + 2 * R;
+    __shared__ float in_s[2][IH * IW];
+    __shared__ float v_s[2][DN_TH * IW];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * DN_TW, oy0 = blockIdx.y * DN_TH;
+    const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
+    const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
+
+    for (int idx = tid; idx < IH * IW; idx += DN_THREADS) {
+        const int ly = idx / IW, lx = idx - ly * IW;
+        const int gy = mirror_idx(2 * oy0 - R + ly, h), gx = mirror_idx(2 * ox0 - R + lx, w);
+        const size_t g = (size_t)gy * in_row_stride + gx;
+        float a = fr[g], b = fd[g];
+        if (OFFSET) { a = a + -128.0f; b = b + -128.0f; }
+        in_s[0][idx] = a;
+        in_s[1][idx] = b;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * DN_TH * IW; idx += DN_THREADS) {
+        const int pl = idx / (DN_TH * IW), rem = idx - pl * (DN_TH * IW);
+        const int oy = rem / IW, c = rem - oy * IW;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * in_s[pl][(2 * oy + k) * IW + c];
+        v_s[pl][rem] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * DN_TH * DN_TW; idx += DN_THREADS) {
+        const int pl = idx / (DN_TH * DN_TW), rem = idx - pl * (DN_TH * DN_TW);
+        const int oy = rem / DN_TW, ox = rem - oy * DN_TW;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * v_s[pl][oy * IW + 2 * ox + k];
+        const int gx = ox0 + ox, gy = oy0 + oy;
+        if (gx < ow && gy < oh) {
+            float *o = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + gx;
+            *o = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- ADM
+constexpr int ADM_TW = 32, ADM_TH = 16, ADM_THREADS = 256;
+constexpr int ADM_SW = ADM_TW + 2, ADM_SH = ADM_TH + 2;      // coefficient slots incl. 1-px halo
+constexpr int ADM_IW = 2 * ADM_SW + 2, ADM_IH = 2 * ADM_SH + 2;  // input pixels the slots need
+constexpr int ADM_SLOTS = ADM_SW * ADM_SH;
+constexpr int ADM_ITEMS = (ADM_SLOTS + ADM_THREADS - 1) / ADM_THREADS;
+
+// One ADM scale, fused (adm.c:132-247 for one value of `scale`): adm_dwt2 x2, adm_decouple, adm_csf x3,
+// adm_cm_thresh, adm_cm and the six adm_sum_cube accumulations.  Only the LL bands go back to HBM.
+template <bool OFFSET>
+__global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                                size_t in_frame_stride, int in_row_stride, int w, int h,
+                                                                float *__restrict__ ll_ref, float *__restrict__ ll_dis,
+                                                                size_t ll_frame_stride, int ll_row_stride,
+                                                                float rfac_hv, float rfac_d,
+                                                                int left, int top, int right, int bottom,
+                                                                double *__restrict__ partial)
+{
+    constexpr int IN_F = ADM_IH * ADM_IW;                     // per plane
+    constexpr int V_F = ADM_SH * ADM_IW;                      // per vertical-pass plane
+    __shared__ __attribute__((aligned(16))) float smem[2 * IN_F + 4 * V_F + 3 * ADM_SLOTS];
+    float *in_r = smem, *in_d = smem + IN_F;
+    float *vlo_r = smem + 2 * IN_F, *vhi_r = vlo_r + V_F, *vlo_d = vhi_r + V_F, *vhi_d = vlo_d + V_F;
+    float *absa = vhi_d + V_F;                                // |csf_a| for h, v, d: [3][ADM_SLOTS]
+    double *red = reinterpret_cast<double *>(smem);
+
+    const int tid = threadIdx.x;
+    const int bw = (w + 1) / 2, bh = (h + 1) / 2;
+    const int cx0 = blockIdx.x * ADM_TW, cy0 = blockIdx.y * ADM_TH;   // first interior coefficient
+    const int ix0 = 2 * (cx0 - 1) - 1, iy0 = 2 * (cy0 - 1) - 1;       // first staged input pixel
+    const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
+    const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
+
+    for (int idx = tid; idx < IN_F; idx += ADM_THREADS) {
+        const int ly = idx / ADM_IW, lx = idx - ly * ADM_IW;
+        const int gy = mirror_idx(iy0 + ly, h), gx = mirror_idx(ix0 + lx, w);
+        const size_t g = (size_t)gy * in_row_stride + gx;
+        float a = fr[g], b = fd[g];
+        if (OFFSET) { a = a + -128.0f; b = b + -128.0f; }
+        in_r[idx] = a;
+        in_d[idx] = b;
+    }
+    __syncthreads();
+
+    // vertical db2 pass at the (mirrored) coefficient rows of every slot row, all staged columns
+    for (int idx = tid; idx < V_F; idx += ADM_THREADS) {
+        const int ty = idx / ADM_IW, lx = idx - ty * ADM_IW;
+        const int cy = mirror_idx(cy0 - 1 + ty, bh);                  // adm_tools.c:241-244 (threshold halo)
+        const int lr = min(max(2 * (cy - (cy0 - 1)), 0), ADM_IH - 4);     // staged row of tap 0 (= pixel 2cy-1)
+        float lo_r = 0.0f, hi_r = 0.0f, lo_d = 0.0f, hi_d = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float pr = in_r[(lr + t) * ADM_IW + lx], pd = in_d[(lr + t) * ADM_IW + lx];
+            lo_r = lo_r + kDb2Lo[t] * pr;
+            hi_r = hi_r + kDb2Hi[t] * pr;
+            lo_d = lo_d + kDb2Lo[t] * pd;
+            hi_d = hi_d + kDb2Hi[t] * pd;
+        }
+        vlo_r[idx] = lo_r; vhi_r[idx] = hi_r; vlo_d[idx] = lo_d; vhi_d[idx] = hi_d;
+    }
+    __syncthreads();
+
+    // horizontal db2 pass + decouple + CSF for every slot
+    float keep_r[ADM_ITEMS][3], keep_o[ADM_ITEMS][3];
+    const float cos1sq = (float)(0.99984769515639127 * 0.99984769515639127);   // cos(1 deg)^2, adm_tools.c:82
+#pragma unroll
+    for (int it = 0; it < ADM_ITEMS; ++it) {
+        const int idx = tid + it * ADM_THREADS;
+        if (idx < ADM_SLOTS) {
+            const int ty = idx / ADM_SW, tx = idx - ty * ADM_SW;
+            const int cxr = cx0 - 1 + tx, cyr = cy0 - 1 + ty;
+            const int cx = mirror_idx(cxr, bw);
+            const int lc = min(max(2 * (cx - (cx0 - 1)), 0), ADM_IW - 4);
+            float ra = 0.0f, rv = 0.0f, rh = 0.0f, rd = 0.0f, da = 0.0f, dv = 0.0f, dh = 0.0f, dd = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = ty * ADM_IW + lc + t;
+                const float lr = vlo_r[o], hr = vhi_r[o], ld = vlo_d[o], hd = vhi_d[o];
+                ra = ra + kDb2Lo[t] * lr;   rv = rv + kDb2Hi[t] * lr;     // band_a, band_v (adm_tools.c:336-361)
+                rh = rh + kDb2Lo[t] * hr;   rd = rd + kDb2Hi[t] * hr;     // band_h, band_d (adm_tools.c:363-388)
+                da = da + kDb2Lo[t] * ld;   dv = dv + kDb2Hi[t] * ld;
+                dh = dh + kDb2Lo[t] * hd;   dd = dd + kDb2Hi[t] * hd;
+            }
+            const bool interior = tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH && cxr < bw && cyr < bh;
+            if (interior && ll_ref) {
+                const size_t g = (size_t)blockIdx.z * ll_frame_stride + (size_t)cyr * ll_row_stride + cxr;
+                ll_ref[g] = ra;
+                ll_dis[g] = da;
+            }
+            // adm_decouple (adm_tools.c:101-173), band order h, v, d
+            const float o3[3] = { rh, rv, rd }, t3[3] = { dh, dv, dd };
+            float rest[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float k = t3[b] / (o3[b] + 1e-30f);
+                k = k < 0.0f ? 0.0f : (k > 1.0f ? 1.0f : k);
+                rest[b] = k * o3[b];
+            }
+            const float dp = rh * dh + rv * dv;
+            const float om = rh * rh + rv * rv;
+            const float tm = dh * dh + dv * dv;
+            const bool aligned = (dp >= 0.0f) && (dp * dp >= cos1sq * om * tm);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float rf = (b == 2) ? rfac_d : rfac_hv;                 // adm_csf, adm_tools.c:190-202
+                const float r = aligned ? t3[b] : rest[b];
+                const float a = t3[b] - r;
+                keep_o[it][b] = rf * o3[b];
+                keep_r[it][b] = rf * r;
+                absa[b * ADM_SLOTS + idx] = fabsf(rf * a);
+            }
+        }
+    }
+    __syncthreads();
+
+    // masking threshold, contrast masking and cube sums for the interior slots
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int it = 0; it < ADM_ITEMS; ++it) {
+        const int idx = tid + it * ADM_THREADS;
+        if (idx < ADM_SLOTS) {
+            const int ty = idx / ADM_SW, tx = idx - ty * ADM_SW;
+            const int cxr = cx0 - 1 + tx, cyr = cy0 - 1 + ty;
+            const bool inwin = tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH &&
+                               cxr >= left && cxr < right && cyr >= top && cyr < bottom;
+            if (inwin) {
+                float thr = 0.0f;                                             // adm_cm_thresh, adm_tools.c:220-257
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int di = -1; di <= 1; ++di)
+#pragma unroll
+                        for (int dj = -1; dj <= 1; ++dj) {
+                            const float c = (di == 0 && dj == 0) ? 1.0f / 15.0f : 1.0f / 30.0f;
+                            a = a + c * absa[b * ADM_SLOTS + (ty + di) * ADM_SW + tx + dj];
+                        }
+                    thr = thr + a;
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float x = fabsf(keep_r[it][b]) - thr;                     // adm_cm, adm_tools.c:278-284
+                    x = x < 0.0f ? 0.0f : x;
+                    acc[b] += (double)(x * x * x);                            // adm_sum_cube, adm_tools.c:68-70
+                    const float y = fabsf(keep_o[it][b]);
+                    acc[3 + b] += (double)(y * y * y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_reduce_store<6, ADM_THREADS / 64>(acc, red, partial + tile * 6);
+}
+
+// ---------------------------------------------------------------- motion
+constexpr int MO_TW = 64, MO_TH = 16, MO_THREADS = 256;
+constexpr int MO_IW = MO_TW + 4, MO_IH = MO_TH + 4;
+
+// 5-tap blur of one tile of one raw ref plane into blur_out[MO_TH*MO_TW] (LDS), convolution.c:78-93 order (y then x)
+__device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int row_stride, int w, int h, int x0, int y0,
+                                           float *in_s, float *v_s, float *blur_out)
+{
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < MO_IH * MO_IW; idx += MO_THREADS) {
+        const int ly = idx / MO_IW, lx = idx - ly * MO_IW;
+        const int gy = mirror_idx(y0 - 2 + ly, h), gx = mirror_idx(x0 - 2 + lx, w);
+        in_s[idx] = plane[(size_t)gy * row_stride + gx] + -128.0f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MO_TH * MO_IW; idx += MO_THREADS) {
+        const int oy = idx / MO_IW, c = idx - oy * MO_IW;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc = acc + kMotion5[k] * in_s[(oy + k) * MO_IW + c];
+        v_s[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MO_TH * MO_TW; idx += MO_THREADS) {
+        const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc = acc + kMotion5[k] * v_s[oy * MO_IW + ox + k];
+        blur_out[idx] = acc;
+    }
+    __syncthreads();
+}
+
+// Motion of every frame of the batch (combo.c:309-326, motion.c:44-60).  Frame f > 0 re-blurs frame f-1
+// from the raw ref already in HBM; frame 0 reads the blurred plane carried over from the previous call.
+// The last frame's blurred tile is written to carry_out for the next call.
+__global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restrict__ ref, size_t frame_stride, int row_stride,
+                                                            int w, int h, int nframes, int has_carry,
+                                                            const float *__restrict__ carry_in, float *__restrict__ carry_out,
+                                                            double *__restrict__ partial)
+{
+    __shared__ float in_s[MO_IH * MO_IW];
+    __shared__ float v_s[MO_TH * MO_IW];
+    __shared__ float cur_s[MO_TH * MO_TW];
+    __shared__ float prev_s[MO_TH * MO_TW];
+    __shared__ double red[MO_THREADS / 64];
+    const int f = blockIdx.z;
+    const int x0 = blockIdx.x * MO_TW, y0 = blockIdx.y * MO_TH;
+    const int tid = threadIdx.x;
+
+    blur5_tile(ref + (size_t)f * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, cur_s);
+    const bool have_prev = (f > 0) || has_carry;
+    if (f > 0) blur5_tile(ref + (size_t)(f - 1) * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, prev_s);
+
+    double acc[1] = { 0.0 };
+    for (int idx = tid; idx < MO_TH * MO_TW; idx += MO_THREADS) {
+        const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
+        const int gx = x0 + ox, gy = y0 + oy;
+        if (gx < w && gy < h) {
+            const float c = cur_s[idx];
+            if (have_prev) {
+                const float p = (f > 0) ? prev_s[idx] : carry_in[(size_t)gy * w + gx];
+                acc[0] += (double)fabsf(p - c);
+            }
+            if (f == nframes - 1 && carry_out) carry_out[(size_t)gy * w + gx] = c;
+        }
+    }
+    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_reduce_store<1, MO_THREADS / 64>(acc, red, partial + tile);
+}
+
+// ---------------------------------------------------------------- final reduction
+__global__ __launch_bounds__(256) void reduce_kernel(const double *__restrict__ partial, vk_reduce_table tab,
+                                                     double *__restrict__ sums /* [frame][VK_NSUMS] */)
+{
+    __shared__ double red[4];
+    const vk_reduce_desc d = tab.d[blockIdx.x];
+    const int f = blockIdx.y;
+    const double *p = partial + d.offset + (size_t)f * d.ntiles * d.k + d.comp;
+    double acc[1] = { 0.0 };
+    for (int t = threadIdx.x; t < d.ntiles; t += 256) acc[0] += p[(size_t)t * d.k];
+    block_reduce_store<1, 4>(acc, red, sums + (size_t)f * VK_NSUMS + blockIdx.x);
+}
+
+// ---------------------------------------------------------------- nu-SVR RBF (svm.cpp:179-247)
+__global__ __launch_bounds__(256) void svm_rbf_kernel(const double *__restrict__ sv, const double *__restrict__ coef, int n_sv,
+                                                      int dim, double gamma, double rho, const double *__restrict__ x,
+                                                      double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const double *xf = x + (size_t)blockIdx.x * dim;
+    double acc[1] = { 0.0 };
+    for (int i = threadIdx.x; i < n_sv; i += 256) {
+        double d2 = 0.0;
+        for (int j = 0; j < dim; ++j) {
+            const double d = xf[j] - sv[(size_t)i * dim + j];
+            d2 += d * d;
+        }
+        acc[0] += coef[i] * exp(-gamma * d2);
+    }
+    __shared__ double total;
+    block_reduce_store<1, 4>(acc, red, &total);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = total - rho;
+}
+
+inline dim3 grid_for(int w, int h, int tw, int th, int nframes) { return dim3((w + tw - 1) / tw, (h + th - 1) / th, nframes); }
+
+}  // namespace
+
+// ---------------------------------------------------------------- launchers
+extern "C" {
+
+int vk_vif_tiles(int w, int h) { return ((w + VIF_TW - 1) / VIF_TW) * ((h + VIF_TH - 1) / VIF_TH); }
+int vk_adm_tiles(int w, int h)
+{
+    const int bw = (w + 1) / 2, bh = (h + 1) / 2;
+    return ((bw + ADM_TW - 1) / ADM_TW) * ((bh + ADM_TH - 1) / ADM_TH);
+}
+int vk_motion_tiles(int w, int h) { return ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH); }
+
+hipError_t vk_launch_vif_stat(int scale, const float *ref, const float *dis, size_t frame_stride, int row_stride,
+                              int w, int h, int nframes, double *partial, hipStream_t s)
+{
+    const dim3 g = grid_for(w, h, VIF_TW, VIF_TH, nframes);
+    switch (scale) {
+    case 0: vif_stat_kernel<17, true><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    case 1: vif_stat_kernel<9, false><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    case 2: vif_stat_kernel<5, false><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    default: vif_stat_kernel<3, false><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    }
+    return hipGetLastError();
+}
+
+// to_scale in 1..3: input is scale to_scale-1 (w x h), output is (w/2) x (h/2)
+hipError_t vk_launch_vif_down(int to_scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+                              int w, int h, float *oref, float *odis, size_t out_frame_stride, int out_row_stride,
+                              int nframes, hipStream_t s)
+{
+    const int ow = w / 2, oh = h / 2;
+    const dim3 g = grid_for(ow, oh, DN_TW, DN_TH, nframes);
+    switch (to_scale) {
+    case 1: vif_down_kernel<9, true><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); break;
+    case 2: vif_down_kernel<5, false><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); break;
+    default: vif_down_kernel<3, false><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+                               int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
+                               float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
+                               double *partial, hipStream_t s)
+{
+    const int bw = (w + 1) / 2, bh = (h + 1) / 2;
+    const dim3 g = grid_for(bw, bh, ADM_TW, ADM_TH, nframes);
+    if (scale == 0)
+        adm_scale_kernel<true><<<g, ADM_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride,
+                                                         ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial);
+    else
+        adm_scale_kernel<false><<<g, ADM_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride,
+                                                          ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial);
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_motion(const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
+                            const float *carry_in, float *carry_out, double *partial, hipStream_t s)
+{
+    const dim3 g = grid_for(w, h, MO_TW, MO_TH, nframes);
+    motion_kernel<<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_reduce(const double *partial, const vk_reduce_table *tab, int nframes, double *sums, hipStream_t s)
+{
+    reduce_kernel<<<dim3(VK_NSUMS, nframes), 256, 0, s>>>(partial, *tab, sums);
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_svm(const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho, const double *x,
+                         int n, double *out, hipStream_t s)
+{
+    svm_rbf_kernel<<<n, 256, 0, s>>>(sv, coef, n_sv, dim, gamma, rho, x, out);
+    return hipGetLastError();
+}
+
+}  // extern "C"
