@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec of full VMAF v0.6.1 (VIF x4 + ADM + motion + nu-SVR) on synthetic 1080p.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[1]): synthetic 1920x1080 yuv420p 8-bit ref/dis pair, luma resident in
+HBM as fp32 (what a read_frame callback delivers) before the timed region starts.  A step = one batch of
+FRAMES_PER_STEP consecutive frames through the whole hot path; default 20 steps x 30 frames = 600 frames.
+Multi-GPU: contiguous frame ranges per rank with a one-frame motion halo (weak scaling: every rank gets
+steps x 30 frames), per-frame atom rows gathered to rank 0 over RCCL, SVR fusion for all frames on rank 0 -
+all inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+vif_stat scale 0, HIP events on the engine's own stream) and `cpu_baseline` (the reference's own C code
+compiled under oracle/_ref when present, else the oracle port, one core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+try:
+    import torch  # first: torch and libvmaf_amd.so must share one HIP runtime
+    import torch.distributed as dist
+except Exception as exc:  # pragma: no cover
+    print(f"bench.py needs torch for device memory / RCCL: {exc}", file=sys.stderr)
+    raise
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import vmaf_amd  # noqa: E402
+from vmaf_amd import synth  # noqa: E402
+
+W, H = 1920, 1080
+FRAMES_PER_STEP = 30
+MODEL = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PATH_BYTES_PER_PX = 26.5        # algorithmic bytes of the whole path per luma pixel
+VIF0_BYTES_PER_PX = 8.0         # dominant kernel: reads the fp32 ref and dis planes once
+
+
+def cpu_baseline(ref, dis, budget_s=20.0, max_frames=64):
+    """Per-frame feature loop on ONE host core, same clip: the compiled reference (oracle/_ref, AVX path,
+    as the reference runs on x86) when it travelled with the repo, else the oracle's C port."""
+    import oracle
+    kind = "reference" if oracle.ref_lib() is not None else "port"
+    n = 0
+    t0 = time.perf_counter()
+    prev = np.zeros((H, W), np.float32)
+    while n < min(max_frames, len(ref)) and (n < 2 or time.perf_counter() - t0 < budget_s):
+        if kind == "reference":
+            _, prev = oracle.ref_frame(ref[n], dis[n], prev, n == 0, avx=1)
+        else:
+            oracle.frame(ref[n], dis[n], prev, n == 0)
+        n += 1
+    dt = time.perf_counter() - t0
+    fps = n / dt
+    sample = f"{n} frames (adm + motion + vif per frame) of the same 1080p clip in {dt:.1f}s"
+    return {"value": round(fps, 3), "unit": "frames/sec", "cores": 1, "kind": kind, "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B, K = FRAMES_PER_STEP, args.steps
+
+    # ---- synthetic clip, resident in HBM as fp32 luma
+    r8, d8 = synth.make_clip(W, H, B, seed=1234)
+    ref, dis = synth.to_luma_f32(r8), synth.to_luma_f32(d8)
+    t_ref, t_dis = torch.from_numpy(ref).to(dev), torch.from_numpy(dis).to(dev)
+    torch.cuda.synchronize()
+
+    eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank)
+    atoms = np.zeros((K, B, 20))
+    scratch = np.zeros((B, 20))
+    for i in range(args.warmup):
+        eng.extract_device(t_ref, t_dis, B, continue_sequence=i > 0, out=scratch)
+    eng.arm_timing()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    if rank > 0:
+        eng.motion_seed(t_ref[B - 1])                  # halo: the frame before this rank's range
+    for k in range(K):
+        eng.extract_device(t_ref, t_dis, B, continue_sequence=(k > 0 or rank > 0), out=atoms[k])
+        ms = eng.last_kernel_ms(1)
+        if ms > 0:
+            k_ms.append(ms)
+    flat = atoms.reshape(K * B, 20)
+    if world > 1:
+        mine = torch.from_numpy(flat).to(dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gathered, dst=0)
+        if rank == 0:
+            flat = torch.cat(gathered).cpu().numpy()
+    if rank == 0:
+        vmaf, _ = vmaf_amd.predict_from_atoms(flat, MODEL, device=local_rank)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * K * B
+        fps = frames / elapsed
+        kernel_ms = float(np.mean(k_ms)) if k_ms else None
+        roof = None
+        if kernel_ms:
+            achieved = VIF0_BYTES_PER_PX * W * H * B / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "vif_stat_kernel<17> (VIF scale 0, fused)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(kernel_ms, 4), "frames_per_launch": B,
+                    "path_achieved_gbs": round(PATH_BYTES_PER_PX * W * H * fps / world / 1e9, 1)}
+        line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",
+                "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "synthetic 1920x1080 yuv420p 8-bit ref/dis pair, vmaf_v0.6.1, fp32 luma resident in HBM",
+                           "frames_per_step_per_gpu": B, "frames_total": frames,
+                           "parallelism": f"frame-range x{world}, 1-frame motion halo" if world > 1 else "single GPU"},
+                "mean_vmaf": round(float(np.mean(vmaf)), 4), "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ref, dis)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

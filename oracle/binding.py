@@ -214,28 +214,34 @@ def ref_adm(ref_off, dis_off):
     return s.value, n.value, dn.value, sc
 
 
-def ref_clip_atoms(ref_frames, dis_frames, avx):
-    """The loop body of wrapper/src/combo.c:236-364 driven through the compiled reference."""
+def ref_frame(ref_raw, dis_raw, prev_blur, first, avx):
+    """One iteration of wrapper/src/combo.c:236-364 through the compiled reference.
+    -> (atoms[20], blurred ref plane to pass as prev_blur for the next frame)."""
     R = ref_lib()
     R.ref_set_cpu(1 if avx else 0)
+    h, w = np.asarray(ref_raw).shape
+    out = np.zeros(20)
+    r = np.asarray(ref_raw, np.float32) + np.float32(-128)
+    d = np.asarray(dis_raw, np.float32) + np.float32(-128)
+    _, n, dn, sc = ref_adm(r, d)
+    out[0], out[1], out[2:10] = n, dn, sc
+    blur = ref_conv_sep(motion_filter(), r, avx)
+    if not first:
+        a, sb = _padded(prev_blur)
+        b, _ = _padded(blur)
+        m = C.c_double()
+        R.compute_motion(_ptr(a), _ptr(b), w, h, sb, sb, C.byref(m))
+        out[10] = m.value
+    s, _, _, sc = ref_vif(r, d, avx)
+    out[11:19], out[19] = sc, s
+    return out, blur
+
+
+def ref_clip_atoms(ref_frames, dis_frames, avx):
+    """The per-frame loop of wrapper/src/combo.c:147-371 driven through the compiled reference."""
     F = len(ref_frames)
-    h, w = ref_frames[0].shape
-    f5 = motion_filter()
     out = np.zeros((F, 20))
     prev = None
     for i in range(F):
-        r = np.asarray(ref_frames[i], np.float32) + np.float32(-128)
-        d = np.asarray(dis_frames[i], np.float32) + np.float32(-128)
-        _, n, dn, sc = ref_adm(r, d)
-        out[i, 0], out[i, 1], out[i, 2:10] = n, dn, sc
-        blur = ref_conv_sep(f5, r, avx)
-        if i > 0:
-            a, sb = _padded(prev)
-            b, _ = _padded(blur)
-            m = C.c_double()
-            R.compute_motion(_ptr(a), _ptr(b), w, h, sb, sb, C.byref(m))
-            out[i, 10] = m.value
-        prev = blur
-        s, _, _, sc = ref_vif(r, d, avx)
-        out[i, 11:19], out[i, 19] = sc, s
+        out[i], prev = ref_frame(ref_frames[i], dis_frames[i], prev, i == 0, avx)
     return out
