@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -62,6 +63,7 @@ struct vmaf_hip_engine {
     hipEvent_t ev_in = nullptr, ev_adm = nullptr, ev_mot = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
     bool timed = false;
+    bool serial = false;
 
     int vw[4], vh[4];              // VIF plane size per scale
     int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
@@ -245,9 +247,13 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
 
     int rc = 0;
     auto cleanup = [&]() { vmaf_hip_engine_destroy(e); return 1; };
-    if (hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->s_adm, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->s_mot, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
+    // VMAF_HIP_SERIAL=1 puts the three chains on one stream (clean per-kernel timings when profiling)
+    const char *ser = getenv("VMAF_HIP_SERIAL");
+    e->serial = ser && *ser && *ser != '0';
+    if (hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
+    if (e->serial) { e->s_adm = e->s_main; e->s_mot = e->s_main; }
+    else if (hipStreamCreateWithFlags(&e->s_adm, hipStreamNonBlocking) != hipSuccess ||
+             hipStreamCreateWithFlags(&e->s_mot, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
     hipEvent_t *evs[] = { &e->ev_in, &e->ev_adm, &e->ev_mot };
     for (auto ev : evs)
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
@@ -293,8 +299,8 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     if (e->sums_host) (void)hipHostFree(e->sums_host);
     hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_t0, e->ev_t1, e->ev_k0, e->ev_k1 };
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
-    hipStream_t ss[] = { e->s_main, e->s_adm, e->s_mot };
-    for (auto s : ss) if (s) (void)hipStreamDestroy(s);
+    if (!e->serial) { if (e->s_adm) (void)hipStreamDestroy(e->s_adm); if (e->s_mot) (void)hipStreamDestroy(e->s_mot); }
+    if (e->s_main) (void)hipStreamDestroy(e->s_main);
     delete e;
 }
 

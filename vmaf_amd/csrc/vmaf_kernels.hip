@@ -50,6 +50,71 @@ __device__ __forceinline__ int mirror_idx(int i, int n)
     return min(max(i, 0), n - 1);
 }
 
+// ---------------------------------------------------------------- tile staging
+// Stage an IH x IW window (IW % 4 == 0) of one or two planes, whose top-left corner is image pixel
+// (gx0, gy0), into LDS (dense rows of IW floats).  Windows inside the image and 16-byte aligned take the
+// float4 path; windows touching the border take the scalar path with the reference's mirror rule.
+// Either way every global load of a thread is in flight before its first LDS write (one memory round
+// trip per tile instead of one per element).
+template <int IH, int IW, int NT, bool OFFSET, bool TWO>
+__device__ __forceinline__ void stage_tile(const float *__restrict__ fr, const float *__restrict__ fd, int row_stride, int w, int h,
+                                           int gx0, int gy0, float *in_r, float *in_d)
+{
+    static_assert(IW % 4 == 0, "staged rows are whole float4s");
+    constexpr int N4 = IH * IW / 4, IT4 = (N4 + NT - 1) / NT;
+    constexpr int N1 = IH * IW, IT1 = (N1 + NT - 1) / NT;
+    const int tid = threadIdx.x;
+    const bool fast = gx0 >= 0 && gy0 >= 0 && gx0 + IW <= w && gy0 + IH <= h && ((gx0 | row_stride) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(fr) | (TWO ? reinterpret_cast<uintptr_t>(fd) : 0)) & 15) == 0;
+    if (fast) {
+        float4 a[IT4], b[IT4];
+#pragma unroll
+        for (int it = 0; it < IT4; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < N4) {
+                const int ly = idx / (IW / 4), l4 = idx - ly * (IW / 4);
+                const size_t g = (size_t)(gy0 + ly) * row_stride + gx0 + 4 * l4;
+                a[it] = *reinterpret_cast<const float4 *>(fr + g);
+                if (TWO) b[it] = *reinterpret_cast<const float4 *>(fd + g);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT4; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < N4) {
+                float4 x = a[it];
+                if (OFFSET) { x.x = x.x + -128.0f; x.y = x.y + -128.0f; x.z = x.z + -128.0f; x.w = x.w + -128.0f; }   // offset_image, combo.c:236-237
+                *reinterpret_cast<float4 *>(in_r + 4 * idx) = x;
+                if (TWO) {
+                    float4 y = b[it];
+                    if (OFFSET) { y.x = y.x + -128.0f; y.y = y.y + -128.0f; y.z = y.z + -128.0f; y.w = y.w + -128.0f; }
+                    *reinterpret_cast<float4 *>(in_d + 4 * idx) = y;
+                }
+            }
+        }
+    } else {
+        float a[IT1], b[IT1];
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < N1) {
+                const int ly = idx / IW, lx = idx - ly * IW;
+                const size_t g = (size_t)mirror_idx(gy0 + ly, h) * row_stride + mirror_idx(gx0 + lx, w);
+                a[it] = fr[g];
+                if (TWO) b[it] = fd[g];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < N1) {
+                in_r[idx] = OFFSET ? a[it] + -128.0f : a[it];
+                if (TWO) in_d[idx] = OFFSET ? b[it] + -128.0f : b[it];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- block reduction (deterministic)
 template <int K, int NWAVES>
 __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *red /* NWAVES*K doubles of LDS */, double *out)
@@ -117,20 +182,26 @@ __device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float
     }
 }
 
-constexpr int VIF_TW = 64, VIF_TH = 32, VIF_THREADS = 320, VIF_SV = 8, VIF_SH = 8;
+// Tile 48 x 32 with 256 threads: the vertical pass has (48 + 2*8) * (32/8) = 256 items at 17 taps and the
+// horizontal pass 32 rows * (48/6) strips = 256 items, so all four waves work in both phases; 48 divides
+// every level of the 1080p / 4K pyramids (1920, 960, 480, 240).
+constexpr int VIF_TW = 48, VIF_TH = 32, VIF_THREADS = 256, VIF_SV = 8, VIF_SH = 6;
 
 template <int FW> struct VifGeom {
     static constexpr int R = FW / 2;
-    static constexpr int IW = VIF_TW + 2 * R;                 // tile + halo, columns
-    static constexpr int IH = VIF_TH + 2 * R;                 // tile + halo, rows
-    static constexpr int VS = (IW + 3) / 4 * 4 + ((((IW + 3) / 4) & 1) ? 0 : 4);   // 4*odd >= IW: conflict-free b128 rows
+    static constexpr int HP = (R + 3) / 4 * 4;                // horizontal halo rounded up to whole float4s
+    static constexpr int IW = VIF_TW + 2 * HP;                // staged columns
+    static constexpr int IH = VIF_TH + 2 * R;                 // staged rows
+    static constexpr int VW = VIF_TW + 2 * R;                 // columns the vertical pass produces
+    static constexpr int VS = ((VW / 2) & 1) ? VW : VW + 2;   // 2*odd >= VW: rows of a half-wave hit distinct bank pairs (ds_read_b64)
     static constexpr int NV = VIF_SH + 2 * R;                 // values one horizontal strip needs
-    static constexpr int NV4 = (NV + 3) / 4;
+    static constexpr int NV2 = NV / 2;
     static constexpr int IN_FLOATS = 2 * IH * IW;
     static constexpr int V_FLOATS = 5 * VIF_TH * VS;
     static constexpr int SMEM_FLOATS = (IN_FLOATS > V_FLOATS ? IN_FLOATS : V_FLOATS);
-    static_assert(IW * (VIF_TH / VIF_SV) <= VIF_THREADS, "one vertical item per thread");
-    static_assert((VIF_TW / VIF_SH - 1) * VIF_SH + 4 * NV4 <= VS, "horizontal reads stay inside a row");
+    static_assert(VW * (VIF_TH / VIF_SV) <= VIF_THREADS, "one vertical item per thread");
+    static_assert(VW % 2 == 0 && NV % 2 == 0 && VIF_SH % 2 == 0, "float2 reads");
+    static_assert(VIF_TH * (VIF_TW / VIF_SH) == VIF_THREADS, "one horizontal item per thread");
 };
 
 // Sequential-tap 1-D filter over a register window: out[o] = sum_k f[k] * v[o + k]
@@ -165,27 +236,19 @@ __global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__re
     const float *fd = dis + (size_t)blockIdx.z * frame_stride;
 
     // ---- stage tile + halo (mirrored at the image border) into LDS
-    for (int idx = tid; idx < IH * IW; idx += VIF_THREADS) {
-        const int ly = idx / IW, lx = idx - ly * IW;
-        const int gy = mirror_idx(y0 - R + ly, h), gx = mirror_idx(x0 - R + lx, w);
-        const size_t g = (size_t)gy * row_stride + gx;
-        float a = fr[g], b = fd[g];
-        if (OFFSET) { a = a + -128.0f; b = b + -128.0f; }    // offset_image, combo.c:236-237
-        in_r[idx] = a;
-        in_d[idx] = b;
-    }
+    stage_tile<IH, IW, VIF_THREADS, OFFSET, true>(fr, fd, row_stride, w, h, x0 - G::HP, y0 - R, in_r, in_d);
     __syncthreads();
 
     // ---- vertical pass: one column, VIF_SV output rows, five quantities, all in registers
     float vo[5][VIF_SV];
-    const int vc = tid % IW, vs = tid / IW;
-    const bool vactive = tid < IW * (VIF_TH / VIF_SV);
+    const int vc = tid % G::VW, vs = tid / G::VW;
+    const bool vactive = tid < G::VW * (VIF_TH / VIF_SV);
     if (vactive) {
         float rv[VIF_SV + 2 * R], dv[VIF_SV + 2 * R], t[VIF_SV + 2 * R];
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) {
-            rv[i] = in_r[(vs * VIF_SV + i) * IW + vc];
-            dv[i] = in_d[(vs * VIF_SV + i) * IW + vc];
+            rv[i] = in_r[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
+            dv[i] = in_d[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
         }
         taps_window<FW, VIF_SV>(rv, vo[0]);
         taps_window<FW, VIF_SV>(dv, vo[1]);
@@ -211,17 +274,17 @@ __global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__re
 
     // ---- horizontal pass + statistic: one row, VIF_SH output columns
     double acc[2] = { 0.0, 0.0 };
-    if (tid < VIF_TH * (VIF_TW / VIF_SH)) {
+    {
         const int row = tid % VIF_TH, strip = tid / VIF_TH;
         float ho[5][VIF_SH];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            float v[4 * G::NV4];
-            const float4 *p = reinterpret_cast<const float4 *>(vout + (q * VIF_TH + row) * VS + strip * VIF_SH);
+            float v[G::NV];
+            const float2 *p = reinterpret_cast<const float2 *>(vout + (q * VIF_TH + row) * VS + strip * VIF_SH);
 #pragma unroll
-            for (int m = 0; m < G::NV4; ++m) {
-                const float4 f4 = p[m];
-                v[4 * m] = f4.x; v[4 * m + 1] = f4.y; v[4 * m + 2] = f4.z; v[4 * m + 3] = f4.w;
+            for (int m = 0; m < G::NV2; ++m) {
+                const float2 f2 = p[m];
+                v[2 * m] = f2.x; v[2 * m + 1] = f2.y;
             }
             taps_window<FW, VIF_SH>(v, ho[q]);
         }
@@ -249,24 +312,16 @@ __global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__res
                                                               float *__restrict__ oref, float *__restrict__ odis,
                                                               size_t out_frame_stride, int out_row_stride, int ow, int oh)
 {
-    constexpr int R = FW / 2;
-    constexpr int IW = 2 * DN_TW + 2 * R, IH = 2 * DN_TH + 2 * R;
-    __shared__ float in_s[2][IH * IW];
+    constexpr int R = FW / 2, HP = (R + 3) / 4 * 4;
+    constexpr int IW = 2 * DN_TW + 2 * HP, IH = 2 * DN_TH + 2 * R;
+    __shared__ __attribute__((aligned(16))) float in_s[2][IH * IW];
     __shared__ float v_s[2][DN_TH * IW];
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * DN_TW, oy0 = blockIdx.y * DN_TH;
     const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
 
-    for (int idx = tid; idx < IH * IW; idx += DN_THREADS) {
-        const int ly = idx / IW, lx = idx - ly * IW;
-        const int gy = mirror_idx(2 * oy0 - R + ly, h), gx = mirror_idx(2 * ox0 - R + lx, w);
-        const size_t g = (size_t)gy * in_row_stride + gx;
-        float a = fr[g], b = fd[g];
-        if (OFFSET) { a = a + -128.0f; b = b + -128.0f; }
-        in_s[0][idx] = a;
-        in_s[1][idx] = b;
-    }
+    stage_tile<IH, IW, DN_THREADS, OFFSET, true>(fr, fd, in_row_stride, w, h, 2 * ox0 - HP, 2 * oy0 - R, in_s[0], in_s[1]);
     __syncthreads();
     for (int idx = tid; idx < 2 * DN_TH * IW; idx += DN_THREADS) {
         const int pl = idx / (DN_TH * IW), rem = idx - pl * (DN_TH * IW);
@@ -282,7 +337,7 @@ __global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__res
         const int oy = rem / DN_TW, ox = rem - oy * DN_TW;
         float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * v_s[pl][oy * IW + 2 * ox + k];
+        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * v_s[pl][oy * IW + 2 * ox + k + (HP - R)];
         const int gx = ox0 + ox, gy = oy0 + oy;
         if (gx < ow && gy < oh) {
             float *o = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + gx;
@@ -294,7 +349,7 @@ __global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__res
 // ---------------------------------------------------------------- ADM
 constexpr int ADM_TW = 32, ADM_TH = 16, ADM_THREADS = 256;
 constexpr int ADM_SW = ADM_TW + 2, ADM_SH = ADM_TH + 2;      // coefficient slots incl. 1-px halo
-constexpr int ADM_IW = 2 * ADM_SW + 2, ADM_IH = 2 * ADM_SH + 2;  // input pixels the slots need
+constexpr int ADM_IW = 2 * ADM_SW + 4, ADM_IH = 2 * ADM_SH + 2;  // staged input: columns from 2*cx0-4 (float4 aligned), rows from 2*cy0-3
 constexpr int ADM_SLOTS = ADM_SW * ADM_SH;
 constexpr int ADM_ITEMS = (ADM_SLOTS + ADM_THREADS - 1) / ADM_THREADS;
 
@@ -320,19 +375,11 @@ __global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__r
     const int tid = threadIdx.x;
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     const int cx0 = blockIdx.x * ADM_TW, cy0 = blockIdx.y * ADM_TH;   // first interior coefficient
-    const int ix0 = 2 * (cx0 - 1) - 1, iy0 = 2 * (cy0 - 1) - 1;       // first staged input pixel
+    const int ix0 = 2 * cx0 - 4, iy0 = 2 * (cy0 - 1) - 1;            // first staged input pixel
     const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
 
-    for (int idx = tid; idx < IN_F; idx += ADM_THREADS) {
-        const int ly = idx / ADM_IW, lx = idx - ly * ADM_IW;
-        const int gy = mirror_idx(iy0 + ly, h), gx = mirror_idx(ix0 + lx, w);
-        const size_t g = (size_t)gy * in_row_stride + gx;
-        float a = fr[g], b = fd[g];
-        if (OFFSET) { a = a + -128.0f; b = b + -128.0f; }
-        in_r[idx] = a;
-        in_d[idx] = b;
-    }
+    stage_tile<ADM_IH, ADM_IW, ADM_THREADS, OFFSET, true>(fr, fd, in_row_stride, w, h, ix0, iy0, in_r, in_d);
     __syncthreads();
 
     // vertical db2 pass at the (mirrored) coefficient rows of every slot row, all staged columns
@@ -363,7 +410,7 @@ __global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__r
             const int ty = idx / ADM_SW, tx = idx - ty * ADM_SW;
             const int cxr = cx0 - 1 + tx, cyr = cy0 - 1 + ty;
             const int cx = mirror_idx(cxr, bw);
-            const int lc = min(max(2 * (cx - (cx0 - 1)), 0), ADM_IW - 4);
+            const int lc = min(max(2 * (cx - cx0) + 3, 0), ADM_IW - 4);  // staged column of tap 0 (= pixel 2cx-1)
             float ra = 0.0f, rv = 0.0f, rh = 0.0f, rd = 0.0f, da = 0.0f, dv = 0.0f, dh = 0.0f, dd = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -448,18 +495,15 @@ __global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__r
 
 // ---------------------------------------------------------------- motion
 constexpr int MO_TW = 64, MO_TH = 16, MO_THREADS = 256;
-constexpr int MO_IW = MO_TW + 4, MO_IH = MO_TH + 4;
+constexpr int MO_HP = 4;                                     // 2-pixel halo rounded up to a float4
+constexpr int MO_IW = MO_TW + 2 * MO_HP, MO_IH = MO_TH + 4;
 
 // 5-tap blur of one tile of one raw ref plane into blur_out[MO_TH*MO_TW] (LDS), convolution.c:78-93 order (y then x)
 __device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int row_stride, int w, int h, int x0, int y0,
                                            float *in_s, float *v_s, float *blur_out)
 {
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < MO_IH * MO_IW; idx += MO_THREADS) {
-        const int ly = idx / MO_IW, lx = idx - ly * MO_IW;
-        const int gy = mirror_idx(y0 - 2 + ly, h), gx = mirror_idx(x0 - 2 + lx, w);
-        in_s[idx] = plane[(size_t)gy * row_stride + gx] + -128.0f;
-    }
+    stage_tile<MO_IH, MO_IW, MO_THREADS, true, false>(plane, nullptr, row_stride, w, h, x0 - MO_HP, y0 - 2, in_s, nullptr);
     __syncthreads();
     for (int idx = tid; idx < MO_TH * MO_IW; idx += MO_THREADS) {
         const int oy = idx / MO_IW, c = idx - oy * MO_IW;
@@ -473,7 +517,7 @@ __device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int 
         const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
         float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) acc = acc + kMotion5[k] * v_s[oy * MO_IW + ox + k];
+        for (int k = 0; k < 5; ++k) acc = acc + kMotion5[k] * v_s[oy * MO_IW + ox + k + (MO_HP - 2)];
         blur_out[idx] = acc;
     }
     __syncthreads();
@@ -487,7 +531,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
                                                             const float *__restrict__ carry_in, float *__restrict__ carry_out,
                                                             double *__restrict__ partial)
 {
-    __shared__ float in_s[MO_IH * MO_IW];
+    __shared__ __attribute__((aligned(16))) float in_s[MO_IH * MO_IW];
     __shared__ float v_s[MO_TH * MO_IW];
     __shared__ float cur_s[MO_TH * MO_TW];
     __shared__ float prev_s[MO_TH * MO_TW];
