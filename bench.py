@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import vmaf_amd  # noqa: E402
-from vmaf_amd import synth  # noqa: E402
+from vmaf_amd import sharding, synth  # noqa: E402
 
 W, H = 1920, 1080
 FRAMES_PER_STEP = 30
@@ -112,13 +112,7 @@ def main():
         ms = eng.last_kernel_ms(1)
         if ms > 0:
             k_ms.append(ms)
-    flat = atoms.reshape(K * B, 20)
-    if world > 1:
-        mine = torch.from_numpy(flat).to(dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)
-        if rank == 0:
-            flat = torch.cat(gathered).cpu().numpy()
+    flat = sharding.gather_rows(atoms.reshape(K * B, 20), dist if world > 1 else None, dev)   # one RCCL gather, rank order = frame order
     if rank == 0:
         vmaf, _ = vmaf_amd.predict_from_atoms(flat, MODEL, device=local_rank)
     barrier()

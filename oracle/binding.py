@@ -245,3 +245,30 @@ def ref_clip_atoms(ref_frames, dis_frames, avx):
     for i in range(F):
         out[i], prev = ref_frame(ref_frames[i], dis_frames[i], prev, i == 0, avx)
     return out
+
+
+class _SvmNode(C.Structure):
+    _fields_ = [("index", C.c_int), ("value", C.c_double)]       # wrapper/src/svm.h:12-16
+
+
+def ref_svm_predict(model_file, x):
+    """svm_load_model + svm_predict of the compiled reference (wrapper/src/svm.cpp:305,468) on rows of x."""
+    so = os.path.join(HERE, "_ref", "libref_svm.so")
+    if not os.path.exists(so):
+        return None
+    S = C.CDLL(so)
+    S.svm_load_model.restype = C.c_void_p
+    S.svm_load_model.argtypes = [C.c_char_p]
+    S.svm_predict.restype = C.c_double
+    S.svm_predict.argtypes = [C.c_void_p, C.POINTER(_SvmNode)]
+    m = S.svm_load_model(model_file.encode())
+    assert m, model_file
+    x = np.asarray(x, np.float64)
+    out = np.zeros(len(x))
+    for f in range(len(x)):
+        nodes = (_SvmNode * (x.shape[1] + 1))()
+        for j in range(x.shape[1]):
+            nodes[j].index, nodes[j].value = j + 1, x[f, j]
+        nodes[x.shape[1]].index = -1                             # terminator, vmaf.cpp:385-389
+        out[f] = S.svm_predict(m, nodes)
+    return out
