@@ -1,0 +1,124 @@
+"""run_vmaf / run_vmaf_in_batch (vmaf_amd/cli.py): argv contract and exit codes on CPU (run_vmaf:29-72,
+run_vmaf_in_batch:31-96), output schema and scores on the GPU (python/src/vmaf/core/result.py:55-293)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from vmaf_amd import cli, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUN = [sys.executable, os.path.join(ROOT, "run_vmaf")]
+BATCH = [sys.executable, os.path.join(ROOT, "run_vmaf_in_batch")]
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "exec.json")))
+ATOMS = json.load(open(os.path.join(ROOT, "tests", "golden", "atoms.json")))
+
+
+def test_run_vmaf_usage_errors_exit_2():
+    for args in ([], ["yuv420p", "64", "48", "a"], ["yuv420p", "x", "48", "a", "b"], ["nv12", "64", "48", "a", "b"],
+                 ["yuv420p", "64", "48", "a", "b", "--out-fmt", "csv"], ["yuv420p", "64", "48", "a", "b", "--pool", "max"],
+                 ["yuv420p", "-1", "48", "a", "b"]):
+        p = subprocess.run(RUN + args, capture_output=True, text=True)
+        assert p.returncode == 2, args
+    assert "usage: run_vmaf fmt width height ref_path dis_path" in subprocess.run(RUN, capture_output=True, text=True).stdout
+
+
+def test_batch_file_grammar(tmp_path):
+    f = tmp_path / "in.txt"
+    f.write_text("# comment\n\nyuv420p 576 324 r0.yuv d0.yuv\nyuv422p10le 64 48 r1.yuv d1.yuv\n")
+    assets, rc = cli.parse_batch_file(str(f))
+    assert rc == 0 and [a.asset_id for a in assets] == [0, 1]
+    assert assets[1].asset_dict == {"width": 64, "height": 48, "yuv_type": "yuv422p10le"}
+    f.write_text("yuv420p 576 324 r0.yuv d0.yuv\nbogus 1 2 a b\n")
+    assert subprocess.run(BATCH + [str(f)], capture_output=True, text=True).returncode == 1
+    assert subprocess.run(BATCH, capture_output=True, text=True).returncode == 2
+    assert subprocess.run(BATCH + [str(f), "--out-fmt", "csv"], capture_output=True, text=True).returncode == 2
+
+
+def test_result_formats_follow_the_reference_schema():
+    a = cli.Asset("cmd", 0, 3, "/x/ref_clip.yuv", "/y/dis_clip.yuv", 576, 324, "yuv420p")
+    r = cli.Result(a, {"VMAF_scores": [70.0, 80.0], "VMAF_feature_adm2_scores": [0.9, 0.95], "VMAF_feature_motion2_scores": [0.0, 3.5]})
+    text = r.to_string().splitlines()
+    assert text[0].startswith('Asset: {"asset_dict": {"height": 324, "width": 576, "yuv_type": "yuv420p"}, "asset_id": 3,')
+    assert text[1] == "Executor: VMAF_VF0.2.4b-0.6.1" and text[2] == "Result:"
+    assert text[3] == "Frame 0: VMAF_feature_adm2_score:0.900000, VMAF_feature_motion2_score:0.000000, VMAF_score:70.000000"
+    assert text[5] == "Aggregate (mean): VMAF_feature_adm2_score:0.925000, VMAF_feature_motion2_score:1.750000, VMAF_score:75.000000"
+    d = r.to_dict()
+    assert list(d.keys()) == ["executorId", "asset", "frames", "aggregate"]
+    assert d["asset"]["identifier"] == "cmd_0_3_ref_clip_576x324_vs_dis_clip_576x324_q_576x324"
+    assert d["frames"][1] == {"frameNum": 1, "VMAF_feature_adm2_score": 0.95, "VMAF_feature_motion2_score": 3.5, "VMAF_score": 80.0}
+    assert d["aggregate"]["method"] == "mean" and d["aggregate"]["VMAF_score"] == 75.0
+    r.set_pool("harmonic_mean")
+    assert abs(r.aggregate("VMAF_scores") - (1.0 / np.mean(1.0 / (np.array([70.0, 80.0]) + 1.0)) - 1.0)) < 1e-12
+    r.set_pool("perc10")
+    assert r.aggregate("VMAF_scores") == np.percentile([70.0, 80.0], 10)
+    xml = r.to_xml()
+    assert '<result executorId="VMAF_VF0.2.4b-0.6.1">' in xml and '<aggregate ' in xml and 'method="perc10"' in xml
+
+
+def test_read_luma_formats(tmp_path):
+    r8, _ = synth.make_clip(64, 48, 2, seed=1)
+    r10, _ = synth.make_clip(64, 48, 2, seed=1, bits=10)
+    for fmt, planes, bits in (("yuv420p", r8, 8), ("yuv444p", r8, 8), ("yuv422p10le", r10, 10)):
+        p = str(tmp_path / f"{fmt}.yuv")
+        synth.write_yuv(p, planes, fmt)
+        got = cli.read_luma(p, fmt, 64, 48)
+        assert np.array_equal(got, synth.to_luma_f32(planes, bits))
+
+
+def _clip_files(tmp_path, clip, fmt, tag=""):
+    kw = dict(ATOMS[clip]["params"])
+    bits = kw.pop("bits", 8)
+    if "cuts" in kw:
+        kw["cuts"] = tuple(kw["cuts"])
+    r, d = synth.make_clip(bits=bits, **kw)
+    rp, dp = str(tmp_path / f"ref{tag}.yuv"), str(tmp_path / f"dis{tag}.yuv")
+    synth.write_yuv(rp, r, fmt)
+    synth.write_yuv(dp, d, fmt)
+    return rp, dp, r.shape[2], r.shape[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default", "phone", "tenbit"])
+def test_run_vmaf_scores_match_reference(name, tmp_path):
+    case = GOLD[name]
+    rp, dp, w, h = _clip_files(tmp_path, case["clip"], case["fmt"])
+    args = [case["fmt"], str(w), str(h), rp, dp, "--out-fmt", "json"] + (["--phone-model"] if name == "phone" else [])
+    p = subprocess.run(RUN + args, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr
+    doc = json.loads(p.stdout)
+    assert doc["executorId"] == "VMAF_VF0.2.4b-0.6.1"
+    assert list(doc["aggregate"].keys()) == ["VMAF_feature_adm2_score", "VMAF_feature_motion2_score"] + \
+        [f"VMAF_feature_vif_scale{s}_score" for s in range(4)] + ["VMAF_score", "method"]
+    for fr, want in zip(doc["frames"], case["frames"]):
+        assert abs(fr["VMAF_score"] - want["vmaf"]) < 1e-3
+        for k in ("adm2", "motion2", "vif_scale0", "vif_scale1", "vif_scale2", "vif_scale3"):
+            assert abs(fr[f"VMAF_feature_{k}_score"] - want[k]) < 1e-4 + 6e-6 * abs(want[k])
+    assert abs(doc["aggregate"]["VMAF_score"] - case["stdout_score"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_run_vmaf_in_batch_text_output(tmp_path):
+    c0, c1 = GOLD["default"], GOLD["harmonic"]
+    r0, d0, w0, h0 = _clip_files(tmp_path, c0["clip"], c0["fmt"], "0")
+    r1, d1, w1, h1 = _clip_files(tmp_path, c1["clip"], c1["fmt"], "1")
+    f = tmp_path / "batch.txt"
+    f.write_text(f"# two pairs\n{c0['fmt']} {w0} {h0} {r0} {d0}\n\n{c1['fmt']} {w1} {h1} {r1} {d1}\n")
+    for extra in ([], ["--parallelize"]):
+        p = subprocess.run(BATCH + [str(f)] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        blocks = p.stdout.split("============================\nAsset ")
+        assert len(blocks) == 3 and blocks[1].startswith("0:\n") and blocks[2].startswith("1:\n")
+        for blk, case in ((blocks[1], c0), (blocks[2], c1)):
+            frames = re.findall(r"^Frame (\d+): (.*)$", blk, flags=re.M)
+            assert len(frames) == len(case["frames"])
+            for (num, body), want in zip(frames, case["frames"]):
+                vals = dict(kv.split(":") for kv in body.split(", "))
+                assert abs(float(vals["VMAF_score"]) - want["vmaf"]) < 1e-3
+                assert abs(float(vals["VMAF_feature_adm2_score"]) - want["adm2"]) < 1e-4
+            agg = re.search(r"^Aggregate \(mean\): .*VMAF_score:([0-9.]+)$", blk, flags=re.M)
+            assert agg and abs(float(agg.group(1)) - np.mean([fr["vmaf"] for fr in case["frames"]])) < 1e-3

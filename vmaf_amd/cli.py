@@ -1,0 +1,353 @@
+"""run_vmaf / run_vmaf_in_batch for the MI355X engine (Python 3).
+
+Same argv contract, exit codes and text / xml / json output schema as the reference's Python-2 launchers
+(run_vmaf:24-140, run_vmaf_in_batch:24-154, python/src/vmaf/core/result.py:55-98,156-293); the
+VmafQualityRunner -> `feature/vmaf all` subprocess -> libsvm chain behind them
+(python/src/vmaf/core/quality_runner.py:295-323) is replaced by vmaf_amd.Engine + predict_from_atoms.
+
+Differences a user can see: content_id/asset_id of run_vmaf are a CRC of the file name (the reference
+uses Python 2's hash()), "workdir" is empty (no work files are made), --local-explain is not offered.
+"""
+import json
+import os
+import re
+import sys
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+FMTS = ['yuv420p', 'yuv422p', 'yuv444p', 'yuv420p10le', 'yuv422p10le', 'yuv444p10le']
+OUT_FMTS = ['text (default)', 'xml', 'json']
+POOL_METHODS = ['mean', 'harmonic_mean', 'min', 'median', 'perc5', 'perc10', 'perc20']
+EXECUTOR_ID = "VMAF_VF0.2.4b-0.6.1"          # mixin.py:62-64 + quality_runner.py:260 / feature_extractor.py VERSION
+
+
+def _opt(argv, begin, name):
+    for i in range(begin, len(argv) - 1):
+        if argv[i] == name:
+            return argv[i + 1]
+    return None
+
+
+def _flag(argv, begin, name):
+    return name in argv[begin:]
+
+
+def _stem(path):
+    return os.path.splitext(os.path.basename(path))[0]
+
+
+# ---------------------------------------------------------------------------------- pooling
+def harmonic_mean(v):
+    return 1.0 / np.mean(1.0 / (np.array(v) + 1.0)) - 1.0
+
+
+def perc5(v):
+    return np.percentile(v, 5)
+
+
+def perc10(v):
+    return np.percentile(v, 10)
+
+
+def perc20(v):
+    return np.percentile(v, 20)
+
+
+POOL_FUNCS = {None: np.mean, 'mean': np.mean, 'harmonic_mean': harmonic_mean, 'min': np.min, 'median': np.median,
+              'perc5': perc5, 'perc10': perc10, 'perc20': perc20}
+POOL_NAMES = {np.mean: 'mean', np.min: 'amin', np.median: 'median'}      # numpy's __name__ of the era ('amin' for np.min)
+
+
+class Asset:
+    def __init__(self, dataset, content_id, asset_id, ref_path, dis_path, width, height, yuv_type):
+        self.dataset, self.content_id, self.asset_id = dataset, content_id, asset_id
+        self.ref_path, self.dis_path = ref_path, dis_path
+        self.asset_dict = {'width': width, 'height': height, 'yuv_type': yuv_type}
+
+    def __str__(self):                           # asset.py:344-440
+        w, h, t = self.asset_dict['width'], self.asset_dict['height'], self.asset_dict['yuv_type']
+        suffix = "" if t == 'yuv420p' else "_" + t
+        return (f"{self.dataset}_{self.content_id}_{self.asset_id}_{_stem(self.ref_path)}_{w}x{h}{suffix}_vs_"
+                f"{_stem(self.dis_path)}_{w}x{h}{suffix}_q_{w}x{h}")
+
+    def to_full_repr(self):                      # asset.py:473-474: json of __dict__, keys sorted
+        d = {'asset_dict': self.asset_dict, 'asset_id': self.asset_id, 'content_id': self.content_id,
+             'dataset': self.dataset, 'dis_path': self.dis_path, 'ref_path': self.ref_path, 'workdir': ""}
+        return json.dumps(d, sort_keys=True)
+
+
+class Result:
+    """result.py:55-293 for the VMAF runner: per-frame lists keyed '<X>_scores', aggregates '<X>_score'."""
+
+    def __init__(self, asset, scores):
+        self.asset, self.scores = asset, scores                      # scores: dict '<X>_scores' -> list
+        self.method = np.mean
+
+    def set_pool(self, name):
+        self.method = POOL_FUNCS[name]
+
+    @property
+    def method_name(self):
+        return POOL_NAMES.get(self.method, getattr(self.method, '__name__', 'mean'))
+
+    def keys(self):
+        return sorted(self.scores)
+
+    def aggregate(self, scores_key):
+        return float(self.method(self.scores[scores_key]))
+
+    def to_string(self):
+        ks = self.keys()
+        s = f"Asset: {self.asset.to_full_repr()}\nExecutor: {EXECUTOR_ID}\nResult:\n"
+        n = len(self.scores[ks[0]])
+        for i in range(n):
+            s += f"Frame {i}: " + ", ".join(f"{k[:-1]}:{self.scores[k][i]:.6f}" for k in ks) + "\n"
+        s += f"Aggregate ({self.method_name}): " + ", ".join(f"{k[:-1]}:{self.aggregate(k):.6f}" for k in ks)
+        return s
+
+    def to_dict(self):
+        ks = self.keys()
+        top = OrderedDict()
+        top['executorId'] = EXECUTOR_ID
+        top['asset'] = {'identifier': str(self.asset)}
+        top['frames'] = []
+        for i in range(len(self.scores[ks[0]])):
+            fr = OrderedDict(frameNum=i)
+            for k in ks:
+                fr[k[:-1]] = float(self.scores[k][i])
+            top['frames'].append(fr)
+        top['aggregate'] = OrderedDict((k[:-1], self.aggregate(k)) for k in ks)
+        top['aggregate']['method'] = self.method_name
+        return top
+
+    def to_json(self):
+        return json.dumps(self.to_dict(), sort_keys=False, indent=4)
+
+    def to_xml(self):
+        from xml.dom import minidom
+        from xml.etree import ElementTree
+        ks = self.keys()
+        top = ElementTree.Element('result')
+        top.set('executorId', EXECUTOR_ID)
+        ElementTree.SubElement(top, 'asset').set('identifier', str(self.asset))
+        frames = ElementTree.SubElement(top, 'frames')
+        for i in range(len(self.scores[ks[0]])):
+            fr = ElementTree.SubElement(frames, 'frame')
+            fr.set('frameNum', str(i))
+            for k in ks:
+                fr.set(k[:-1], repr(float(self.scores[k][i])))
+        agg = ElementTree.SubElement(top, 'aggregate')
+        agg.set('method', self.method_name)
+        for k in ks:
+            agg.set(k[:-1], repr(self.aggregate(k)))
+        return minidom.parseString(ElementTree.tostring(top, 'utf-8')).toprettyxml(indent="  ")
+
+
+# ---------------------------------------------------------------------------------- scoring
+def read_luma(path, fmt, width, height):
+    """Memory-map a raw YUV file and return the luma planes [F,h,w] as float32 in 8-bit units
+    (feature/src/common/file_io.c:86-172: 10-bit / 4.0), skipping chroma (frame.c:80-124)."""
+    ten = fmt.endswith('10le')
+    n = width * height
+    chroma = {'yuv420p': n // 2, 'yuv422p': n, 'yuv444p': 2 * n}[fmt.replace('10le', '')]
+    dt = np.dtype('<u2') if ten else np.dtype(np.uint8)
+    frame_samples = n + chroma
+    total = os.path.getsize(path) // dt.itemsize
+    frames = total // frame_samples
+    if frames * frame_samples < total and total - frames * frame_samples >= n:
+        frames += 1                                    # a last frame with short chroma is still scored (frame.c:83-87)
+    mm = np.memmap(path, dtype=dt, mode='r')
+    out = np.empty((frames, height, width), np.float32)
+    for f in range(frames):
+        y = np.asarray(mm[f * frame_samples:f * frame_samples + n]).reshape(height, width)
+        out[f] = (y.astype(np.float64) / 4.0).astype(np.float32) if ten else y.astype(np.float32)
+    return out
+
+
+def score_asset(asset, model_path, phone_model, device=0, engine_cache=None):
+    """-> Result.  The feature + fusion hot path on the GPU; no CPU fallback."""
+    from . import binding
+    w, h, fmt = asset.asset_dict['width'], asset.asset_dict['height'], asset.asset_dict['yuv_type']
+    ref = read_luma(asset.ref_path, fmt, w, h)
+    dis = read_luma(asset.dis_path, fmt, w, h)
+    frames = min(len(ref), len(dis))
+    key = (w, h, device)
+    eng = engine_cache.get(key) if engine_cache is not None else None
+    if eng is None:
+        batch = int(min(64, max(4, (128 << 20) // (w * h * 4))))
+        eng = binding.Engine(w, h, max_batch=batch, device=device)
+        if engine_cache is not None:
+            engine_cache[key] = eng
+    atoms = eng.extract(ref[:frames], dis[:frames])
+    model_path = model_path or binding.DEFAULT_MODEL
+    names = _model_feature_names(model_path)
+    vm, feats = binding.predict_from_atoms(atoms, model_path, enable_transform=phone_model, device=device,
+                                           n_features=len(names))
+    scores = {name + 's': feats[:, j].tolist() for j, name in enumerate(names)}
+    scores['VMAF_scores'] = vm.tolist()
+    return Result(asset, scores)
+
+
+def _model_feature_names(model_path):
+    text = open(model_path).read()
+    seen = []
+    for m in re.finditer(r"S'(VMAF_feature_\w+_score)'", text):
+        if m.group(1) not in seen:
+            seen.append(m.group(1))
+    # the pickle lists feature_names in model order; the first mention of each name is inside that list
+    return seen
+
+
+# ---------------------------------------------------------------------------------- run_vmaf
+def _usage_run_vmaf(prog):
+    print("usage: " + prog + " fmt width height ref_path dis_path [--model model_path] [--out-fmt out_fmt] [--phone-model]\n")
+    print("fmt:\n\t" + "\n\t".join(FMTS) + "\n")
+    print("out_fmt:\n\t" + "\n\t".join(OUT_FMTS) + "\n")
+
+
+def _print_result(result, out_fmt):
+    if out_fmt == 'xml':
+        print(result.to_xml())
+    elif out_fmt == 'json':
+        print(result.to_json())
+    else:
+        print(result.to_string())
+
+
+def run_vmaf_main(argv):
+    prog = os.path.basename(argv[0])
+    if len(argv) < 6:
+        _usage_run_vmaf(prog)
+        return 2
+    try:
+        fmt, width, height, ref_file, dis_file = argv[1], int(argv[2]), int(argv[3]), argv[4], argv[5]
+    except ValueError:
+        _usage_run_vmaf(prog)
+        return 2
+    if width < 0 or height < 0:
+        print(f"width and height must be non-negative, but are {width} and {height}")
+        _usage_run_vmaf(prog)
+        return 2
+    if fmt not in FMTS:
+        _usage_run_vmaf(prog)
+        return 2
+    model_path = _opt(argv, 6, '--model')
+    out_fmt = _opt(argv, 6, '--out-fmt')
+    if out_fmt not in (None, 'xml', 'json', 'text'):
+        _usage_run_vmaf(prog)
+        return 2
+    pool_method = _opt(argv, 6, '--pool')
+    if pool_method not in (None,) + tuple(POOL_METHODS):
+        print('--pool can only have option among {}'.format(', '.join(POOL_METHODS)))
+        return 2
+    phone_model = _flag(argv, 6, '--phone-model')
+    cid = zlib.crc32(_stem(ref_file).encode()) % (10 ** 16)
+    asset = Asset("cmd", cid, cid, ref_file, dis_file, width, height, fmt)
+    result = score_asset(asset, model_path, phone_model)
+    result.set_pool(pool_method)
+    _print_result(result, out_fmt)
+    return 0
+
+
+# ---------------------------------------------------------------------------------- run_vmaf_in_batch
+def _usage_batch(prog):
+    print("usage: " + prog + " input_file [--model model_path] [--out-fmt out_fmt] [--parallelize] [--phone-model]\n")
+    print("out_fmt:\n\t" + "\n\t".join(OUT_FMTS) + "\n")
+    print("input_file contains lines of:")
+    print("\tfmt width height ref_path dis_path\\n")
+    print("fmt:\n\t" + "\n\t".join(FMTS) + "\n")
+
+
+def parse_batch_file(path, prog="run_vmaf_in_batch"):
+    """-> (assets, 0) or (None, 1) on a bad line (run_vmaf_in_batch:60-96)."""
+    assets = []
+    with open(path, "rt") as f:
+        for line in f.readlines():
+            if re.match(r"^#", line):
+                print("Skip commented line: {}".format(line))
+                continue
+            if re.match(r"[\s]+", line):
+                continue
+            mo = re.match(r"([\S]+) ([0-9]+) ([0-9]+) ([\S]+) ([\S]+)", line)
+            if not mo or mo.group(1) not in FMTS:
+                print("Unknown format: {}".format(line))
+                _usage_batch(prog)
+                return None, 1
+            assets.append(Asset("cmd", 0, len(assets), mo.group(4), mo.group(5), int(mo.group(2)), int(mo.group(3)), mo.group(1)))
+    return assets, 0
+
+
+def _batch_worker(device, items, model_path, phone_model, q):
+    cache = {}
+    for idx, asset in items:
+        q.put((idx, score_asset(asset, model_path, phone_model, device=device, engine_cache=cache).scores))
+    q.put(None)
+
+
+def run_vmaf_in_batch_main(argv):
+    prog = os.path.basename(argv[0])
+    if len(argv) < 2:
+        _usage_batch(prog)
+        return 2
+    model_path = _opt(argv, 2, '--model')
+    out_fmt = _opt(argv, 2, '--out-fmt')
+    if out_fmt not in (None, 'xml', 'json', 'text'):
+        _usage_batch(prog)
+        return 2
+    pool_method = _opt(argv, 2, '--pool')
+    if pool_method not in (None,) + tuple(POOL_METHODS):
+        print('--pool can only have option among {}'.format(', '.join(POOL_METHODS)))
+        return 2
+    parallelize = _flag(argv, 2, '--parallelize')
+    phone_model = _flag(argv, 2, '--phone-model')
+    assets, rc = parse_batch_file(argv[1], prog)
+    if rc:
+        return rc
+
+    results = [None] * len(assets)
+    from . import binding, sharding
+    ndev = binding.device_count() if parallelize else 1
+    if parallelize and ndev > 1 and len(assets) > 1:
+        # whole pairs per GPU, longest first, one worker process per GPU; results back in input order
+        # (the reference forks one process per asset, executor.py:100-123 - here one per device)
+        import multiprocessing as mp
+        costs = [a.asset_dict['width'] * a.asset_dict['height'] * max(1, os.path.getsize(a.ref_path)) for a in assets]
+        parts = sharding.assign_pairs(costs, ndev)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_batch_worker, args=(d, [(i, assets[i]) for i in parts[d]], model_path, phone_model, q))
+                 for d in range(ndev) if parts[d]]
+        for p in procs:
+            p.start()
+        done = 0
+        while done < len(procs):
+            item = q.get()
+            if item is None:
+                done += 1
+            else:
+                results[item[0]] = Result(assets[item[0]], item[1])
+        for p in procs:
+            p.join()
+    else:
+        cache = {}
+        for i, a in enumerate(assets):
+            results[i] = score_asset(a, model_path, phone_model, engine_cache=cache)
+
+    for result in results:
+        result.set_pool(pool_method)
+        if out_fmt == 'xml':
+            print(result.to_xml())
+        elif out_fmt == 'json':
+            print(result.to_json())
+        else:
+            print('============================')
+            print('Asset {asset_id}:'.format(asset_id=result.asset.asset_id))
+            print('============================')
+            print(result.to_string())
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(run_vmaf_main(sys.argv))
