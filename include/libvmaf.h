@@ -14,7 +14,8 @@
  *                  Returns 0 = frame delivered, 2 = end of stream, 1 = failure (combo.c:149-157)
  *   model_path     <name>.pkl (protocol-0 pickle); the libsvm model is read from <model_path>.model
  *   log_path       NULL = no log; log_fmt "json" = JSON, anything else = XML (vmaf.cpp:675-750)
- *   disable_avx    accepted and ignored (there is no CPU convolution path in this build)
+ *   disable_avx    0: sum the filter taps in the order of the reference's AVX kernels (its default on x86);
+ *                  non-zero: in the order of its scalar loops (libvmaf.cpp:56-61) - both reproduced bit for bit
  *   enable_transform | phone_model   apply the model's score_transform (libvmaf.cpp:37-39)
  *   do_psnr / do_ssim / do_ms_ssim   not features of vmaf_v0.6.1 and not built here: non-zero is an error
  *   pool_method    NULL | "mean" | "min" | "harmonic_mean"

@@ -45,6 +45,16 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
 void vmaf_hip_engine_destroy(vmaf_hip_engine *e);
 
 /*
+ * Summation order of the separable convolutions (VIF filters, motion blur).  The reference has two and
+ * picks one per call: its AVX kernels (default on x86) or the scalar loops (compute_vmaf's disable_avx,
+ * wrapper/src/libvmaf.cpp:56-61; the process-global `cpu` read by feature/src/vif_tools.c:279 and
+ * feature/src/common/convolution.c:82).  The two differ at 1e-7 relative per pixel, which VIF's per-pixel
+ * branches can amplify to several 1e-3 VMAF on noisy content, so the engine reproduces both bit for bit
+ * per pixel: order 1 = AVX order (default), 0 = scalar order.
+ */
+int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order);
+
+/*
  * Extract the 20 atoms of `nframes` CONSECUTIVE frames.  Replaces, per frame, the body of the
  * reference loop wrapper/src/combo.c:236-364:
  *   offset_image(-128) x2          (feature/src/common/file_io.c:177-198)

@@ -41,19 +41,39 @@ def _clip(w, h, frames, bits=8, **kw):
     return synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
 
 
-@pytest.mark.parametrize("w,h,frames", [(64, 48, 5), (577, 325, 3), (576, 324, 3), (200, 32, 2), (33, 130, 2), (1920, 1080, 2)])
-def test_atoms_match_oracle(w, h, frames):
+ORDERS = {"avx": oracle.ORDER_AVX, "scalar": oracle.ORDER_SCALAR}
+
+
+@pytest.mark.parametrize("order", ["avx", "scalar"])
+@pytest.mark.parametrize("w,h,frames", [(64, 48, 5), (577, 325, 3), (576, 324, 3), (200, 32, 2), (33, 130, 2), (100, 75, 2),
+                                        (1920, 1080, 2)])
+def test_atoms_match_oracle(w, h, frames, order):
+    """Both summation orders of the reference (AVX kernels = its default on x86, scalar loops = disable_avx)."""
     ref, dis = _clip(w, h, frames, seed=w + h)
-    want = oracle.clip_atoms(ref, dis, oracle.ORDER_SCALAR)
-    with vmaf_amd.Engine(w, h, max_batch=4) as e:
+    want = oracle.clip_atoms(ref, dis, ORDERS[order])
+    with vmaf_amd.Engine(w, h, max_batch=4, order=order) as e:
         got = e.extract(ref, dis)
-    _check(got, want, f"{w}x{h}")
+    _check(got, want, f"{w}x{h} {order}")
+
+
+def test_noisy_image_where_the_two_orders_diverge(golden_dir):
+    """tests/golden/images/100007: the reference's own AVX and scalar paths differ by 3.7e-3 VMAF on this pair
+    (65.415667 vs 65.412008); the engine has to land on the right one in each mode."""
+    ref = np.fromfile(os.path.join(golden_dir, "images", "100007.yuv"), np.uint8)[:481 * 321].reshape(1, 321, 481).astype(np.float32)
+    dis = np.fromfile(os.path.join(golden_dir, "images", "100007_noisy.yuv"), np.uint8)[:481 * 321].reshape(1, 321, 481).astype(np.float32)
+    got = {}
+    for order in ("avx", "scalar"):
+        with vmaf_amd.Engine(481, 321, order=order) as e:
+            a = e.extract(ref, dis)
+        _check(a, oracle.clip_atoms(ref, dis, ORDERS[order]), order)
+        got[order] = vmaf_amd.predict_from_atoms(a)[0][0]
+    assert abs(got["avx"] - 65.415667) < 1e-4 and abs(got["scalar"] - 65.412008) < 1e-4
 
 
 def test_ten_bit_input():
     ref, dis = _clip(320, 180, 3, bits=10, seed=5)
     assert np.any(ref != np.round(ref))            # quarter steps really present
-    want = oracle.clip_atoms(ref, dis)
+    want = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX)
     with vmaf_amd.Engine(320, 180, max_batch=8) as e:
         got = e.extract(ref, dis)
     _check(got, want, "10-bit")
@@ -66,7 +86,7 @@ def test_batch_size_does_not_change_results():
     with vmaf_amd.Engine(160, 96, max_batch=2) as e:
         pieces = e.extract(ref, dis)
     assert np.array_equal(whole, pieces)
-    _check(whole, oracle.clip_atoms(ref, dis), "cuts")
+    _check(whole, oracle.clip_atoms(ref, dis, oracle.ORDER_AVX), "cuts")
 
 
 def test_motion_halo_matches_unsharded_run():
@@ -84,7 +104,7 @@ def test_motion_halo_matches_unsharded_run():
 
 def test_static_and_identical_clip():
     ref, _ = _clip(128, 80, 3, seed=2, static=True)
-    want = oracle.clip_atoms(ref, ref)
+    want = oracle.clip_atoms(ref, ref, oracle.ORDER_AVX)
     with vmaf_amd.Engine(128, 80) as e:
         got = e.extract(ref, ref)
     _check(got, want, "identical")
@@ -97,7 +117,7 @@ def test_flat_frames():
     """Reference corner case python/test/feature_test.py:659-719 (flat Y=0 vs Y=10), at reduced size."""
     ref = np.zeros((2, 72, 128), np.float32)
     dis = np.full((2, 72, 128), 10.0, np.float32)
-    want = oracle.clip_atoms(ref, dis)
+    want = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX)
     with vmaf_amd.Engine(128, 72) as e:
         got = e.extract(ref, dis)
     fg, fw = _feats(got), _feats(want)
@@ -131,7 +151,7 @@ def test_svm_predict_matches_oracle(model_path):
                                 dict(pool_method="min")])
 def test_compute_vmaf_end_to_end(model_path, tmp_path, kw):
     ref, dis = _clip(320, 180, 6, seed=21, cuts=(3,))
-    atoms = oracle.clip_atoms(ref, dis)
+    atoms = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX)
     pkl, svm = oracle.load_pkl_model(model_path), oracle.load_svm_model(model_path + ".model")
     per_frame, feats = oracle.vmaf_from_atoms(atoms, pkl, svm, enable_transform=kw.get("phone_model", False),
                                               disable_clip=kw.get("disable_clip", False))

@@ -49,6 +49,7 @@ def load_library():
     L.vmaf_hip_engine_create.argtypes = [C.POINTER(vp), i, i, i, i]
     L.vmaf_hip_engine_destroy.argtypes = [vp]
     L.vmaf_hip_engine_destroy.restype = None
+    L.vmaf_hip_engine_set_conv_order.argtypes = [vp, i]
     for name in ("vmaf_hip_extract_device", "vmaf_hip_extract_host", "vmaf_hip_extract_device_async",
                  "vmaf_hip_extract_host_async"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, sz, i, i, _dp]
@@ -80,7 +81,7 @@ def device_count():
 class Engine:
     """One GPU, one frame geometry, one video's motion state (vmaf_hip_engine)."""
 
-    def __init__(self, width, height, max_batch=16, device=0):
+    def __init__(self, width, height, max_batch=16, device=0, order="avx"):
         self.L = load_library()
         self.w, self.h, self.max_batch, self.device = width, height, max_batch, device
         h = C.c_void_p()
@@ -88,6 +89,8 @@ class Engine:
             raise VmafHipError(_err(self.L))
         self._h = h
         self._keep = None
+        if self.L.vmaf_hip_engine_set_conv_order(h, {"avx": 1, "scalar": 0}[order]):
+            raise VmafHipError(_err(self.L))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -190,7 +193,7 @@ def predict_from_atoms(atoms, model_path=DEFAULT_MODEL, disable_clip=False, enab
 
 def compute_vmaf_from_arrays(ref, dis, fmt="yuv420p", model_path=DEFAULT_MODEL, log_path=None, log_fmt=None,
                              disable_clip=False, enable_transform=False, phone_model=False, pool_method=None,
-                             do_psnr=False, do_ssim=False, do_ms_ssim=False):
+                             do_psnr=False, do_ssim=False, do_ms_ssim=False, disable_avx=False):
     """Drive compute_vmaf() through its read_frame callback from float32 luma arrays [F,h,w]
     (un-offset, 8-bit units) - the way an external C caller such as FFmpeg's libvmaf filter does."""
     L = load_library()
@@ -215,7 +218,7 @@ def compute_vmaf_from_arrays(ref, dis, fmt="yuv420p", model_path=DEFAULT_MODEL, 
     err = C.create_string_buffer(1024)
     enc = lambda s: s.encode() if s is not None else None  # noqa: E731
     rc = L.compute_vmaf_noexcept(C.byref(score), fmt.encode(), w, h, READ_FRAME(cb), None, model_path.encode(), enc(log_path),
-                                 enc(log_fmt), int(disable_clip), 0, int(enable_transform), int(phone_model), int(do_psnr),
+                                 enc(log_fmt), int(disable_clip), int(disable_avx), int(enable_transform), int(phone_model), int(do_psnr),
                                  int(do_ssim), int(do_ms_ssim), enc(pool_method), err, 1024)
     if rc:
         raise VmafHipError(err.value.decode(errors="replace"))

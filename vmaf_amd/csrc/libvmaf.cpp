@@ -65,7 +65,7 @@ std::vector<int> parse_devices()
 // the engines (one per GPU); each batch after the first gets its motion halo from the previous
 // batch's last ref frame.  Fills atoms [frames][20].
 void extract_atoms(int (*read_frame)(float *, float *, float *, int, void *), void *user_data, int w, int h,
-                   std::vector<double> &atoms)
+                   bool scalar_order, std::vector<double> &atoms)
 {
     if (w <= 0 || h <= 0) throw VmafException("wrong width " + std::to_string(w) + " or height " + std::to_string(h) + ".");
     const size_t stride = ((size_t)w * 4 + 31) / 32 * 32;          // ALIGN_CEIL, combo.c:106
@@ -83,6 +83,7 @@ void extract_atoms(int (*read_frame)(float *, float *, float *, int, void *), vo
         vmaf_hip_engine *e = nullptr;
         if (vmaf_hip_engine_create(&e, devices[g], w, h, batch)) throw VmafException(vmaf_hip_last_error());
         guard.engines.push_back(e);
+        if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : 1)) throw VmafException(vmaf_hip_last_error());
         for (int b = 0; b < 2; ++b) {
             float **pp[2] = { &slots[g].ref[b], &slots[g].dis[b] };
             for (auto p : pp) {
@@ -290,8 +291,8 @@ void write_logs(const char *log_path, const char *log_fmt, const char *model_pat
 }
 
 double run_vmaf(const char *fmt, int width, int height, int (*read_frame)(float *, float *, float *, int, void *), void *user_data,
-                const char *model_path, const char *log_path, const char *log_fmt, bool disable_clip, bool enable_transform,
-                bool do_psnr, bool do_ssim, bool do_ms_ssim, const char *pool_method)
+                const char *model_path, const char *log_path, const char *log_fmt, bool disable_clip, bool disable_avx,
+                bool enable_transform, bool do_psnr, bool do_ssim, bool do_ms_ssim, const char *pool_method)
 {
     (void)fmt;
     std::printf("Start calculating VMAF score...\n");             // vmaf.cpp:638
@@ -306,7 +307,7 @@ double run_vmaf(const char *fmt, int width, int height, int (*read_frame)(float 
 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> atoms;
-    extract_atoms(read_frame, user_data, width, height, atoms);
+    extract_atoms(read_frame, user_data, width, height, disable_avx, atoms);
     const size_t F = atoms.size() / kAtoms;
     if (F == 0) throw VmafException("no frames delivered by read_frame");
     std::vector<double> vmaf;
@@ -338,8 +339,8 @@ double compute_vmaf(char *fmt, int width, int height, int (*read_frame)(float *,
                     char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform,
                     int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method)
 {
-    (void)disable_avx;                                             // libvmaf.cpp:56-61: no CPU convolution here
-    return run_vmaf(fmt, width, height, read_frame, user_data, model_path, log_path, log_fmt, disable_clip != 0,
+    // disable_avx selects the reference's scalar summation order instead of its AVX order (libvmaf.cpp:56-61)
+    return run_vmaf(fmt, width, height, read_frame, user_data, model_path, log_path, log_fmt, disable_clip != 0, disable_avx != 0,
                     (enable_transform || phone_model), do_psnr != 0, do_ssim != 0, do_ms_ssim != 0, pool_method);
 }
 

@@ -196,8 +196,11 @@ VmafModel load_vmaf_model(const std::string &pkl_path)
         throw std::runtime_error(std::string("Error loading model (.pkl): ") + e.what());
     }
     const PValPtr &model_type = need("model_type"), &feature_names = need("feature_names"), &norm_type = need("norm_type");
-    const PValPtr &slopes = need("slopes"), &intercepts = need("intercepts");
-    const PValPtr &score_clip = need("score_clip"), &score_transform = need("score_transform");
+    // a key the dict lacks reads as None, as ptools' Val operator[] gives the reference (vmaf.cpp:83-86)
+    static const PValPtr none = std::make_shared<PVal>();
+    auto opt = [&](const char *k) -> const PValPtr & { const PValPtr *q = (*md)->find(k); return q ? *q : none; };
+    const PValPtr &slopes = opt("slopes"), &intercepts = opt("intercepts");
+    const PValPtr &score_clip = opt("score_clip"), &score_transform = opt("score_transform");
 
     // vmaf.cpp:95-136
     if (model_type->kind != PVal::STR || model_type->str != "LIBSVMNUSVR") {

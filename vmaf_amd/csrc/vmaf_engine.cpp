@@ -64,6 +64,7 @@ struct vmaf_hip_engine {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
     bool timed = false;
     bool serial = false;
+    int order = 1;                 // convolution tap order: 1 = reference AVX path (default), 0 = scalar path
 
     int vw[4], vh[4];              // VIF plane size per scale
     int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
@@ -75,7 +76,7 @@ struct vmaf_hip_engine {
     float *stage_ref = nullptr, *stage_dis = nullptr;
     double *partials = nullptr, *sums_dev = nullptr, *sums_host = nullptr;
     size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
-    int tiles_vif[4], tiles_adm[4], tiles_mot;
+    int tiles_vif[4], tiles_vif_border[4], tiles_adm[4], tiles_mot;
     float rfac[8];
     int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
 
@@ -147,12 +148,15 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     for (int sc = 0; sc < 4; ++sc) {
         if (sc > 0) {
             const size_t ofs = (size_t)e->vw[sc] * e->vh[sc];
-            HIP_TRY(vk_launch_vif_down(sc, cr, cd, cfs, crs, e->vw[sc - 1], e->vh[sc - 1], e->vif_ref[sc], e->vif_dis[sc], ofs,
+            HIP_TRY(vk_launch_vif_down(sc, e->order, cr, cd, cfs, crs, e->vw[sc - 1], e->vh[sc - 1], e->vif_ref[sc], e->vif_dis[sc], ofs,
                                        e->vw[sc], nframes, e->s_main));
             cr = e->vif_ref[sc]; cd = e->vif_dis[sc]; cfs = ofs; crs = e->vw[sc];
         }
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0, e->s_main));
-        HIP_TRY(vk_launch_vif_stat(sc, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc], e->s_main));
+        HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc], e->s_main));
+        if (e->order == 1)   // the border frame of the AVX order: its blocks' partials follow the tile kernel's
+            HIP_TRY(vk_launch_vif_border(sc, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes,
+                                         e->partials + e->part_off_vif[sc] + (size_t)nframes * e->tiles_vif[sc] * 2, e->s_main));
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1, e->s_main));
     }
 
@@ -170,7 +174,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     HIP_TRY(hipEventRecord(e->ev_adm, e->s_adm));
 
     // ---- motion (combo.c:309-326) on s_mot
-    HIP_TRY(vk_launch_motion(d_ref, fs, rs, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
+    HIP_TRY(vk_launch_motion(e->order, d_ref, fs, rs, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
                              e->partials + e->part_off_mot, e->s_mot));
     HIP_TRY(hipEventRecord(e->ev_mot, e->s_mot));
     e->carry_cur = 1 - e->carry_cur;
@@ -182,10 +186,12 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     vk_reduce_table tab;
     int q = 0;
     for (int sc = 0; sc < 4; ++sc)
-        for (int c = 0; c < 2; ++c) tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c };
+        for (int c = 0; c < 2; ++c)
+            tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c, e->part_off_vif[sc] + (size_t)nframes * e->tiles_vif[sc] * 2,
+                           e->order == 1 ? e->tiles_vif_border[sc] : 0 };
     for (int sc = 0; sc < 4; ++sc)
-        for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c };
-    tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0 };
+        for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c, 0, 0 };
+    tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0, 0, 0 };
     HIP_TRY(vk_launch_reduce(e->partials, &tab, nframes, e->sums_dev, e->s_main));
     HIP_TRY(hipMemcpyAsync(e->sums_host, e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
     if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1, e->s_main));
@@ -272,7 +278,12 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     if (!rc) rc |= alloc_planes(&e->stage_dis, B * width * height);
 
     size_t off = 0;
-    for (int s = 0; s < 4; ++s) { e->tiles_vif[s] = vk_vif_tiles(e->vw[s], e->vh[s]); e->part_off_vif[s] = off; off += B * e->tiles_vif[s] * 2; }
+    for (int s = 0; s < 4; ++s) {
+        e->tiles_vif[s] = vk_vif_tiles(e->vw[s], e->vh[s]);
+        e->tiles_vif_border[s] = vk_vif_border_tiles(s, e->vw[s], e->vh[s]);
+        e->part_off_vif[s] = off;
+        off += B * (e->tiles_vif[s] + e->tiles_vif_border[s]) * 2;
+    }
     for (int s = 0; s < 4; ++s) { e->tiles_adm[s] = vk_adm_tiles(e->aw[s], e->ah[s]); e->part_off_adm[s] = off; off += B * e->tiles_adm[s] * 6; }
     e->tiles_mot = vk_motion_tiles(width, height); e->part_off_mot = off; off += B * e->tiles_mot;
     e->part_total = off;
@@ -302,6 +313,14 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     if (!e->serial) { if (e->s_adm) (void)hipStreamDestroy(e->s_adm); if (e->s_mot) (void)hipStreamDestroy(e->s_mot); }
     if (e->s_main) (void)hipStreamDestroy(e->s_main);
     delete e;
+}
+
+int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order)
+{
+    if (!e) return fail("null engine");
+    if (order != 0 && order != 1) return fail("conv order %d is neither 0 (scalar) nor 1 (avx)", order);
+    e->order = order;
+    return 0;
 }
 
 int vmaf_hip_engine_sync(vmaf_hip_engine *e)
@@ -380,7 +399,7 @@ int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t r
     if (row_stride_bytes % 4 || row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
     HIP_TRY(hipSetDevice(e->device));
     // one-frame motion launch without predecessor: only its carry_out side effect is used
-    HIP_TRY(vk_launch_motion(d_ref, 0, (int)(row_stride_bytes / 4), e->w, e->h, 1, 0, e->carry[e->carry_cur],
+    HIP_TRY(vk_launch_motion(e->order, d_ref, 0, (int)(row_stride_bytes / 4), e->w, e->h, 1, 0, e->carry[e->carry_cur],
                              e->carry[1 - e->carry_cur], e->partials + e->part_off_mot, e->s_main));
     e->carry_cur = 1 - e->carry_cur;
     e->carry_valid = true;

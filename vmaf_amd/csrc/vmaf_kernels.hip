@@ -1,14 +1,21 @@
 // vmaf_kernels.hip - hand-written gfx950 (MI355X / CDNA4) kernels for the VMAF v0.6.1 feature path.
 //
 // Numerics policy: every multiply and add in the stencils rounds separately (build with
-// -ffp-contract=off) and filter taps are accumulated left to right, i.e. the arithmetic of the
-// reference's scalar path (feature/src/vif_tools.c:292-328, common/convolution.c:26-76,
-// adm_tools.c:308-389).  Per-pixel values are therefore bit-identical to the reference run with
-// disable_avx; only the final plane sums differ (fp64 tree here, fp32 row-then-total there).
+// -ffp-contract=off) and the filter taps are summed in one of the reference's own two orders, chosen
+// like the reference chooses (compute_vmaf's disable_avx flag, libvmaf.cpp:56-61):
+//   ORDER_AVX    (default) the order of the reference's AVX path, which is what it runs on x86:
+//                interior samples use four interleaved partial sums, border rows/columns the scalar
+//                order (feature/src/common/convolution_avx.c:787-837, SURVEY.md note N1)
+//   ORDER_SCALAR taps accumulated left to right everywhere (vif_tools.c:292-328, convolution.c:26-76)
+// ADM has a single order in the reference (adm_tools.c:308-389).  Per-pixel values are therefore
+// bit-identical to the reference in the same mode; only the final plane sums differ (fp64 tree here,
+// fp32 row-then-total there).  In ORDER_AVX the fused VIF kernel computes the pure vector order and leaves
+// the thin frame of pixels that the reference computes (partly) with the scalar order to vif_border_kernel.
 //
 // Kernels (one launch covers a whole batch of frames: blockIdx.z = frame):
 //   vif_stat_kernel<FW>   fused: tile+halo of ref/dis -> LDS, vertical pass of {r,d,r^2,d^2,rd},
 //                         horizontal pass, per-pixel VIF statistic, block-reduced num/den
+//   vif_border_kernel<FW> ORDER_AVX only: the border frame (top/bottom R rows, left R / right ~8 columns)
 //   vif_down_kernel<FW>   blur with the next scale's filter evaluated at even samples only
 //   adm_scale_kernel      fused: db2 DWT (ref+dis) in LDS, decouple, CSF, 3x3 masking threshold,
 //                         masked cube sums over the centre window, LL bands to HBM
@@ -39,6 +46,54 @@ __device__ constexpr float kDb2Hi[4] = { -0.129409522550921f, -0.224143868041857
 template <int FW> __device__ __forceinline__ constexpr float vif_tap(int k)
 {
     return FW == 17 ? kVif17[k] : FW == 9 ? kVif9[k] : FW == 5 ? kVif5[k] : kVif3[k];
+}
+// MOTION selects FILTER_5_s (motion_tools.h), which differs from VIF's 5-tap table in the 8th digit
+template <int FW, bool MOTION> __device__ __forceinline__ constexpr float ftap(int k) { return MOTION ? kMotion5[k] : vif_tap<FW>(k); }
+
+constexpr int ORDER_SCALAR = 0, ORDER_AVX = 1;
+
+// One output sample from p[0], p[st], .., p[(FW-1)*st], taps accumulated left to right from 0.
+template <int FW, bool MOTION> __device__ __forceinline__ float taps_seq_at(const float *p, int st)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < FW; ++k) acc = acc + ftap<FW, MOTION>(k) * p[k * st];
+    return acc;
+}
+
+// Same sample in the interior order of the reference's AVX kernels (convolution_avx.c:225-270, :347-392,
+// :408-437, generic :116-205): passes of up to 9 taps; inside a pass tap k goes to partial sum k%4, the pass
+// value is (s0+s2)+(s1+s3); pass values are added in order, the first one to +0.
+template <int FW, bool MOTION> __device__ __forceinline__ float taps_avx_at(const float *p, int st)
+{
+    float total = 0.0f;
+#pragma unroll
+    for (int x = 0; x < FW; x += 9) {
+        const int n = FW - x < 9 ? FW - x : 9;
+        float sm[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k < n) {
+                const float prod = ftap<FW, MOTION>(x + k) * p[(x + k) * st];
+                sm[k & 3] = (k < 4) ? prod : sm[k & 3] + prod;
+            }
+        }
+        const float pass = (sm[0] + sm[2]) + (sm[1] + sm[3]);
+        total = total + pass;
+    }
+    return total;
+}
+
+// Where the reference's AVX path uses its vector kernels (convolution_avx.c:799-836):
+//   vertical pass:   rows r <= i < h - r, columns j < floor8(w)
+//   horizontal pass: columns r <= j < r + floor8(w) - ceil8(r + 1)
+__host__ __device__ __forceinline__ bool avx_row_ok(int gy, int h, int r) { return gy >= r && gy < h - r; }
+__host__ __device__ __forceinline__ bool avx_vcol_ok(int gx, int w) { return gx < (w & ~7); }
+__host__ __device__ __forceinline__ int avx_hcol_end(int w, int r) { return r + (w & ~7) - ((r + 1 + 7) & ~7); }
+// A pixel whose value involves no scalar-order sample at all (every other pixel is "border frame")
+__host__ __device__ __forceinline__ bool avx_pure_pixel(int gx, int gy, int w, int h, int r)
+{
+    return avx_row_ok(gy, h, r) && gx >= r && gx < avx_hcol_end(w, r);
 }
 
 // Mirror rule of every stencil on the path (vif_tools.c:301, adm_tools.c:241-248); the final
@@ -204,23 +259,19 @@ template <int FW> struct VifGeom {
     static_assert(VIF_TH * (VIF_TW / VIF_SH) == VIF_THREADS, "one horizontal item per thread");
 };
 
-// Sequential-tap 1-D filter over a register window: out[o] = sum_k f[k] * v[o + k]
-template <int FW, int NOUT>
+// 1-D filter over a register window: out[o] = sum_k f[k] * v[o + k], in the scalar or the vector order
+template <int FW, int NOUT, int ORDER>
 __device__ __forceinline__ void taps_window(const float *v, float *out)
 {
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * v[o + k];
-        out[o] = acc;
-    }
+    for (int o = 0; o < NOUT; ++o)
+        out[o] = (ORDER == ORDER_SCALAR) ? taps_seq_at<FW, false>(v + o, 1) : taps_avx_at<FW, false>(v + o, 1);
 }
 
 // Fused VIF scale kernel. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products,
 // three filtered moments, vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.
-template <int FW, bool OFFSET>
-__global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+template <int FW, bool OFFSET, int ORDER>
+__global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                                size_t frame_stride, int row_stride, int w, int h,
                                                                double *__restrict__ partial)
 {
@@ -250,17 +301,17 @@ __global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__re
             rv[i] = in_r[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
             dv[i] = in_d[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
         }
-        taps_window<FW, VIF_SV>(rv, vo[0]);
-        taps_window<FW, VIF_SV>(dv, vo[1]);
+        taps_window<FW, VIF_SV, ORDER>(rv, vo[0]);
+        taps_window<FW, VIF_SV, ORDER>(dv, vo[1]);
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * rv[i];
-        taps_window<FW, VIF_SV>(t, vo[2]);
+        taps_window<FW, VIF_SV, ORDER>(t, vo[2]);
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = dv[i] * dv[i];
-        taps_window<FW, VIF_SV>(t, vo[3]);
+        taps_window<FW, VIF_SV, ORDER>(t, vo[3]);
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * dv[i];
-        taps_window<FW, VIF_SV>(t, vo[4]);
+        taps_window<FW, VIF_SV, ORDER>(t, vo[4]);
     }
     __syncthreads();                                          // input tile fully consumed: alias it
     float *vout = smem;
@@ -286,7 +337,7 @@ __global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__re
                 const float2 f2 = p[m];
                 v[2 * m] = f2.x; v[2 * m + 1] = f2.y;
             }
-            taps_window<FW, VIF_SH>(v, ho[q]);
+            taps_window<FW, VIF_SH, ORDER>(v, ho[q]);
         }
         const int gy = y0 + row;
 #pragma unroll
@@ -294,7 +345,9 @@ __global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__re
             const int gx = x0 + strip * VIF_SH + o;
             float n, d;
             vif_pixel(ho[0][o], ho[1][o], ho[2][o], ho[3][o], ho[4][o], n, d);
-            if (gx < w && gy < h) { acc[0] += (double)n; acc[1] += (double)d; }
+            // ORDER_AVX: the border frame belongs to vif_border_kernel
+            const bool mine = gx < w && gy < h && (ORDER == ORDER_SCALAR || avx_pure_pixel(gx, gy, w, h, R));
+            if (mine) { acc[0] += (double)n; acc[1] += (double)d; }
         }
     }
     __syncthreads();                                          // vout fully consumed: alias for the reduction
@@ -302,11 +355,100 @@ __global__ __launch_bounds__(VIF_THREADS) void vif_stat_kernel(const float *__re
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
 }
 
+// ---------------------------------------------------------------- VIF border frame (ORDER_AVX)
+constexpr int BD_T = 16, BD_THREADS = 256;
+
+struct BorderGeom { int nx, ny, ty_b, tx_r, nrs, ncs, ntiles; };
+// 16x16 tiles that intersect the frame of pixels which is not avx_pure_pixel: tile rows {0} u [ty_b, ny)
+// completely, and in the other rows tile columns {0} u [tx_r, nx).
+__host__ __device__ inline BorderGeom border_geom(int w, int h, int r)
+{
+    BorderGeom g;
+    g.nx = (w + BD_T - 1) / BD_T;
+    g.ny = (h + BD_T - 1) / BD_T;
+    const int hb = h - r > 0 ? h - r : 0, he = avx_hcol_end(w, r) > 0 ? avx_hcol_end(w, r) : 0;
+    g.ty_b = hb / BD_T > 1 ? hb / BD_T : 1;
+    g.tx_r = he / BD_T > 1 ? he / BD_T : 1;
+    if (g.ty_b > g.ny) g.ty_b = g.ny;
+    if (g.tx_r > g.nx) g.tx_r = g.nx;
+    g.nrs = 1 + g.ny - g.ty_b;
+    g.ncs = 1 + g.nx - g.tx_r;
+    g.ntiles = g.nrs * g.nx + (g.ty_b - 1) * g.ncs;
+    return g;
+}
+
+// The pixels of one VIF scale whose value involves scalar-order samples in the reference's AVX path: same
+// arithmetic as vif_stat_kernel, but every sample picks its order exactly as convolution_f32_avx_s_1d does
+// (convolution_avx.c:806-836).  About 2 % of the pixels, so a plain LDS-direct formulation.
+template <int FW, bool OFFSET>
+__global__ __launch_bounds__(BD_THREADS) void vif_border_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                                size_t frame_stride, int row_stride, int w, int h,
+                                                                double *__restrict__ partial)
+{
+    constexpr int R = FW / 2, HP = (R + 3) / 4 * 4;
+    constexpr int IW = BD_T + 2 * HP, IH = BD_T + 2 * R, VW = BD_T + 2 * R;
+    __shared__ __attribute__((aligned(16))) float pl[5][IH * IW];       // r, d, then r*r, d*d, r*d
+    __shared__ float vout[5][BD_T * VW];
+    __shared__ double red[(BD_THREADS / 64) * 2];
+    const BorderGeom g = border_geom(w, h, R);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int tx, ty;
+    if (b < g.nrs * g.nx) {
+        const int rr = b / g.nx;
+        tx = b - rr * g.nx;
+        ty = rr == 0 ? 0 : g.ty_b + rr - 1;
+    } else {
+        const int bb = b - g.nrs * g.nx, c = bb % g.ncs;
+        ty = 1 + bb / g.ncs;
+        tx = c == 0 ? 0 : g.tx_r + c - 1;
+    }
+    const int x0 = tx * BD_T, y0 = ty * BD_T;
+    const float *fr = ref + (size_t)blockIdx.z * frame_stride;
+    const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+    stage_tile<IH, IW, BD_THREADS, OFFSET, true>(fr, fd, row_stride, w, h, x0 - HP, y0 - R, pl[0], pl[1]);
+    __syncthreads();
+    for (int idx = tid; idx < IH * IW; idx += BD_THREADS) {
+        const float a = pl[0][idx], c = pl[1][idx];
+        pl[2][idx] = a * a;
+        pl[3][idx] = c * c;
+        pl[4][idx] = a * c;
+    }
+    __syncthreads();
+    const int hend = avx_hcol_end(w, R);
+    for (int idx = tid; idx < 5 * BD_T * VW; idx += BD_THREADS) {
+        const int q = idx / (BD_T * VW), rem = idx - q * (BD_T * VW);
+        const int oy = rem / VW, c = rem - oy * VW;
+        const float *src = &pl[q][oy * IW + c + (HP - R)];
+        const bool avx = avx_row_ok(y0 + oy, h, R) && avx_vcol_ok(mirror_idx(x0 - R + c, w), w);
+        vout[q][rem] = avx ? taps_avx_at<FW, false>(src, IW) : taps_seq_at<FW, false>(src, IW);
+    }
+    __syncthreads();
+    double acc[2] = { 0.0, 0.0 };
+    {
+        const int oy = tid / BD_T, ox = tid - oy * BD_T;
+        const int gx = x0 + ox, gy = y0 + oy;
+        if (gx < w && gy < h && !avx_pure_pixel(gx, gy, w, h, R)) {
+            const bool avx = gx >= R && gx < hend;
+            float f[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float *src = &vout[q][oy * VW + ox];
+                f[q] = avx ? taps_avx_at<FW, false>(src, 1) : taps_seq_at<FW, false>(src, 1);
+            }
+            float n, d;
+            vif_pixel(f[0], f[1], f[2], f[3], f[4], n, d);
+            acc[0] = (double)n;
+            acc[1] = (double)d;
+        }
+    }
+    block_reduce_store<2, BD_THREADS / 64>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2);
+}
+
 // ---------------------------------------------------------------- VIF pyramid step
 constexpr int DN_TW = 32, DN_TH = 16, DN_THREADS = 256;
 
 // vif.c:157-186: next = dec2(blur_{filter[scale+1]}(cur)); only the even samples are evaluated.
-template <int FW, bool OFFSET>
+template <int FW, bool OFFSET, int ORDER>
 __global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                               size_t in_frame_stride, int in_row_stride, int w, int h,
                                                               float *__restrict__ oref, float *__restrict__ odis,
@@ -326,18 +468,18 @@ __global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__res
     for (int idx = tid; idx < 2 * DN_TH * IW; idx += DN_THREADS) {
         const int pl = idx / (DN_TH * IW), rem = idx - pl * (DN_TH * IW);
         const int oy = rem / IW, c = rem - oy * IW;
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * in_s[pl][(2 * oy + k) * IW + c];
-        v_s[pl][rem] = acc;
+        const float *src = &in_s[pl][(2 * oy) * IW + c];
+        const bool avx = ORDER == ORDER_AVX && avx_row_ok(2 * (oy0 + oy), h, R) && avx_vcol_ok(mirror_idx(2 * ox0 - HP + c, w), w);
+        v_s[pl][rem] = avx ? taps_avx_at<FW, false>(src, IW) : taps_seq_at<FW, false>(src, IW);
     }
     __syncthreads();
     for (int idx = tid; idx < 2 * DN_TH * DN_TW; idx += DN_THREADS) {
         const int pl = idx / (DN_TH * DN_TW), rem = idx - pl * (DN_TH * DN_TW);
         const int oy = rem / DN_TW, ox = rem - oy * DN_TW;
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < FW; ++k) acc = acc + vif_tap<FW>(k) * v_s[pl][oy * IW + 2 * ox + k + (HP - R)];
+        const float *src = &v_s[pl][oy * IW + 2 * ox + (HP - R)];
+        const int sx = 2 * (ox0 + ox);                                  // source column of this output
+        const bool avx = ORDER == ORDER_AVX && sx >= R && sx < avx_hcol_end(w, R);
+        const float acc = avx ? taps_avx_at<FW, false>(src, 1) : taps_seq_at<FW, false>(src, 1);
         const int gx = ox0 + ox, gy = oy0 + oy;
         if (gx < ow && gy < oh) {
             float *o = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + gx;
@@ -499,6 +641,7 @@ constexpr int MO_HP = 4;                                     // 2-pixel halo rou
 constexpr int MO_IW = MO_TW + 2 * MO_HP, MO_IH = MO_TH + 4;
 
 // 5-tap blur of one tile of one raw ref plane into blur_out[MO_TH*MO_TW] (LDS), convolution.c:78-93 order (y then x)
+template <int ORDER>
 __device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int row_stride, int w, int h, int x0, int y0,
                                            float *in_s, float *v_s, float *blur_out)
 {
@@ -507,18 +650,15 @@ __device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int 
     __syncthreads();
     for (int idx = tid; idx < MO_TH * MO_IW; idx += MO_THREADS) {
         const int oy = idx / MO_IW, c = idx - oy * MO_IW;
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) acc = acc + kMotion5[k] * in_s[(oy + k) * MO_IW + c];
-        v_s[idx] = acc;
+        const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + oy, h, 2) && avx_vcol_ok(mirror_idx(x0 - MO_HP + c, w), w);
+        v_s[idx] = avx ? taps_avx_at<5, true>(&in_s[oy * MO_IW + c], MO_IW) : taps_seq_at<5, true>(&in_s[oy * MO_IW + c], MO_IW);
     }
     __syncthreads();
     for (int idx = tid; idx < MO_TH * MO_TW; idx += MO_THREADS) {
         const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) acc = acc + kMotion5[k] * v_s[oy * MO_IW + ox + k + (MO_HP - 2)];
-        blur_out[idx] = acc;
+        const float *src = &v_s[oy * MO_IW + ox + (MO_HP - 2)];
+        const bool avx = ORDER == ORDER_AVX && x0 + ox >= 2 && x0 + ox < avx_hcol_end(w, 2);
+        blur_out[idx] = avx ? taps_avx_at<5, true>(src, 1) : taps_seq_at<5, true>(src, 1);
     }
     __syncthreads();
 }
@@ -526,6 +666,7 @@ __device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int 
 // Motion of every frame of the batch (combo.c:309-326, motion.c:44-60).  Frame f > 0 re-blurs frame f-1
 // from the raw ref already in HBM; frame 0 reads the blurred plane carried over from the previous call.
 // The last frame's blurred tile is written to carry_out for the next call.
+template <int ORDER>
 __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restrict__ ref, size_t frame_stride, int row_stride,
                                                             int w, int h, int nframes, int has_carry,
                                                             const float *__restrict__ carry_in, float *__restrict__ carry_out,
@@ -540,9 +681,9 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
     const int x0 = blockIdx.x * MO_TW, y0 = blockIdx.y * MO_TH;
     const int tid = threadIdx.x;
 
-    blur5_tile(ref + (size_t)f * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, cur_s);
+    blur5_tile<ORDER>(ref + (size_t)f * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, cur_s);
     const bool have_prev = (f > 0) || has_carry;
-    if (f > 0) blur5_tile(ref + (size_t)(f - 1) * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, prev_s);
+    if (f > 0) blur5_tile<ORDER>(ref + (size_t)(f - 1) * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, prev_s);
 
     double acc[1] = { 0.0 };
     for (int idx = tid; idx < MO_TH * MO_TW; idx += MO_THREADS) {
@@ -571,6 +712,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const double *__restrict__ 
     const double *p = partial + d.offset + (size_t)f * d.ntiles * d.k + d.comp;
     double acc[1] = { 0.0 };
     for (int t = threadIdx.x; t < d.ntiles; t += 256) acc[0] += p[(size_t)t * d.k];
+    const double *p2 = partial + d.offset2 + (size_t)f * d.ntiles2 * d.k + d.comp;
+    for (int t = threadIdx.x; t < d.ntiles2; t += 256) acc[0] += p2[(size_t)t * d.k];
     block_reduce_store<1, 4>(acc, red, sums + (size_t)f * VK_NSUMS + blockIdx.x);
 }
 
@@ -611,31 +754,59 @@ int vk_adm_tiles(int w, int h)
 }
 int vk_motion_tiles(int w, int h) { return ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH); }
 
-hipError_t vk_launch_vif_stat(int scale, const float *ref, const float *dis, size_t frame_stride, int row_stride,
+int vk_vif_border_tiles(int scale, int w, int h)
+{
+    static const int fw[4] = { 17, 9, 5, 3 };
+    return border_geom(w, h, fw[scale] / 2).ntiles;
+}
+
+hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, hipStream_t s)
 {
     const dim3 g = grid_for(w, h, VIF_TW, VIF_TH, nframes);
+#define VIF_STAT(FW, OFF)                                                                                                   \
+    if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); \
+    else vif_stat_kernel<FW, OFF, ORDER_AVX><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial)
     switch (scale) {
-    case 0: vif_stat_kernel<17, true><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    case 1: vif_stat_kernel<9, false><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    case 2: vif_stat_kernel<5, false><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    default: vif_stat_kernel<3, false><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    case 0: VIF_STAT(17, true); break;
+    case 1: VIF_STAT(9, false); break;
+    case 2: VIF_STAT(5, false); break;
+    default: VIF_STAT(3, false); break;
+    }
+#undef VIF_STAT
+    return hipGetLastError();
+}
+
+// ORDER_AVX only: the border frame of one scale; partial receives vk_vif_border_tiles() * 2 doubles per frame
+hipError_t vk_launch_vif_border(int scale, const float *ref, const float *dis, size_t frame_stride, int row_stride,
+                                int w, int h, int nframes, double *partial, hipStream_t s)
+{
+    const dim3 g(vk_vif_border_tiles(scale, w, h), 1, nframes);
+    switch (scale) {
+    case 0: vif_border_kernel<17, true><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    case 1: vif_border_kernel<9, false><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    case 2: vif_border_kernel<5, false><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
+    default: vif_border_kernel<3, false><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
     }
     return hipGetLastError();
 }
 
 // to_scale in 1..3: input is scale to_scale-1 (w x h), output is (w/2) x (h/2)
-hipError_t vk_launch_vif_down(int to_scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+hipError_t vk_launch_vif_down(int to_scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
                               int w, int h, float *oref, float *odis, size_t out_frame_stride, int out_row_stride,
                               int nframes, hipStream_t s)
 {
     const int ow = w / 2, oh = h / 2;
     const dim3 g = grid_for(ow, oh, DN_TW, DN_TH, nframes);
+#define VIF_DOWN(FW, OFF)                                                                                                   \
+    if (order == ORDER_SCALAR) vif_down_kernel<FW, OFF, ORDER_SCALAR><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); \
+    else vif_down_kernel<FW, OFF, ORDER_AVX><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh)
     switch (to_scale) {
-    case 1: vif_down_kernel<9, true><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); break;
-    case 2: vif_down_kernel<5, false><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); break;
-    default: vif_down_kernel<3, false><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); break;
+    case 1: VIF_DOWN(9, true); break;
+    case 2: VIF_DOWN(5, false); break;
+    default: VIF_DOWN(3, false); break;
     }
+#undef VIF_DOWN
     return hipGetLastError();
 }
 
@@ -655,11 +826,14 @@ hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, si
     return hipGetLastError();
 }
 
-hipError_t vk_launch_motion(const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
+hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
                             const float *carry_in, float *carry_out, double *partial, hipStream_t s)
 {
     const dim3 g = grid_for(w, h, MO_TW, MO_TH, nframes);
-    motion_kernel<<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
+    if (order == ORDER_SCALAR)
+        motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
+    else
+        motion_kernel<ORDER_AVX><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
     return hipGetLastError();
 }
 
