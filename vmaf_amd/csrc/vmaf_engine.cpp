@@ -146,18 +146,18 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     size_t cfs = fs;
     int crs = rs;
     for (int sc = 0; sc < 4; ++sc) {
-        if (sc > 0) {
-            const size_t ofs = (size_t)e->vw[sc] * e->vh[sc];
-            HIP_TRY(vk_launch_vif_down(sc, e->order, cr, cd, cfs, crs, e->vw[sc - 1], e->vh[sc - 1], e->vif_ref[sc], e->vif_dis[sc], ofs,
-                                       e->vw[sc], nframes, e->s_main));
-            cr = e->vif_ref[sc]; cd = e->vif_dis[sc]; cfs = ofs; crs = e->vw[sc];
-        }
+        // scale sc: statistic + (sc < 3) the next scale's planes, both from one read of the current planes
+        float *nr = sc < 3 ? e->vif_ref[sc + 1] : nullptr, *nd = sc < 3 ? e->vif_dis[sc + 1] : nullptr;
+        const size_t nfs = sc < 3 ? (size_t)e->vw[sc + 1] * e->vh[sc + 1] : 0;
+        const int nrs = sc < 3 ? e->vw[sc + 1] : 0;
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0, e->s_main));
-        HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc], e->s_main));
+        HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc],
+                                   nr, nd, nfs, nrs, e->s_main));
+        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1, e->s_main));
         if (e->order == 1)   // the border frame of the AVX order: its blocks' partials follow the tile kernel's
             HIP_TRY(vk_launch_vif_border(sc, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes,
                                          e->partials + e->part_off_vif[sc] + (size_t)nframes * e->tiles_vif[sc] * 2, e->s_main));
-        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1, e->s_main));
+        cr = nr; cd = nd; cfs = nfs; crs = nrs;
     }
 
     // ---- ADM chain (adm.c:125-254) on s_adm

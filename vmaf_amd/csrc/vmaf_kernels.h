@@ -32,13 +32,11 @@ int vk_motion_tiles(int w, int h);
 
 // order: 0 = the reference's scalar tap order (disable_avx), 1 = its AVX order (default on x86)
 hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
-                              int w, int h, int nframes, double *partial, hipStream_t s);
+                              int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
+                              int out_row_stride, hipStream_t s);
 int vk_vif_border_tiles(int scale, int w, int h);
 hipError_t vk_launch_vif_border(int scale, const float *ref, const float *dis, size_t frame_stride, int row_stride,
                                 int w, int h, int nframes, double *partial, hipStream_t s);
-hipError_t vk_launch_vif_down(int to_scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
-                              int w, int h, float *oref, float *odis, size_t out_frame_stride, int out_row_stride,
-                              int nframes, hipStream_t s);
 hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,

@@ -14,9 +14,9 @@
 //
 // Kernels (one launch covers a whole batch of frames: blockIdx.z = frame):
 //   vif_stat_kernel<FW>   fused: tile+halo of ref/dis -> LDS, vertical pass of {r,d,r^2,d^2,rd},
-//                         horizontal pass, per-pixel VIF statistic, block-reduced num/den
+//                         horizontal pass, per-pixel VIF statistic, block-reduced num/den; from the same tile
+//                         the next scale's input (blur with the next filter at even samples only)
 //   vif_border_kernel<FW> ORDER_AVX only: the border frame (top/bottom R rows, left R / right ~8 columns)
-//   vif_down_kernel<FW>   blur with the next scale's filter evaluated at even samples only
 //   adm_scale_kernel      fused: db2 DWT (ref+dis) in LDS, decouple, CSF, 3x3 masking threshold,
 //                         masked cube sums over the centre window, LL bands to HBM
 //   motion_kernel         5-tap blur of frame f and f-1 (or carried blurred plane), SAD
@@ -251,6 +251,10 @@ template <int FW> struct VifGeom {
     static constexpr int VS = ((VW / 2) & 1) ? VW : VW + 2;   // 2*odd >= VW: rows of a half-wave hit distinct bank pairs (ds_read_b64)
     static constexpr int NV = VIF_SH + 2 * R;                 // values one horizontal strip needs
     static constexpr int NV2 = NV / 2;
+    static constexpr int DFW = FW == 17 ? 9 : FW == 9 ? 5 : FW == 5 ? 3 : 0;   // filter of the next scale (vif.c:137-138,160-161)
+    static constexpr int RD = DFW / 2;
+    static constexpr int DVW = VIF_TW + 2 * RD;               // columns the decimation's vertical pass produces
+    static constexpr int D_FLOATS = DFW ? 2 * (VIF_TH / 2) * DVW : 0;
     static constexpr int IN_FLOATS = 2 * IH * IW;
     static constexpr int V_FLOATS = 5 * VIF_TH * VS;
     static constexpr int SMEM_FLOATS = (IN_FLOATS > V_FLOATS ? IN_FLOATS : V_FLOATS);
@@ -270,15 +274,21 @@ __device__ __forceinline__ void taps_window(const float *v, float *out)
 
 // Fused VIF scale kernel. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products,
 // three filtered moments, vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.
+// From the same staged tile it also produces the next scale's input (vif.c:157-186): blur with the NEXT
+// scale's filter, evaluated at even rows/columns only, so ref/dis are read from HBM once per scale.
 template <int FW, bool OFFSET, int ORDER>
 __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                                size_t frame_stride, int row_stride, int w, int h,
-                                                               double *__restrict__ partial)
+                                                               double *__restrict__ partial,
+                                                               float *__restrict__ oref, float *__restrict__ odis,
+                                                               size_t out_frame_stride, int out_row_stride)
 {
     using G = VifGeom<FW>;
     constexpr int R = G::R, IW = G::IW, IH = G::IH, VS = G::VS;
-    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS + 16];
+    constexpr int DFW = G::DFW, RD = G::RD, DVW = G::DVW;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS + 16 + G::D_FLOATS];
     float *in_r = smem, *in_d = smem + IH * IW;
+    float *dv_s = smem + G::SMEM_FLOATS + 16;                 // decimation: vertical results, [2][TH/2][DVW]
     double *red = reinterpret_cast<double *>(smem);           // reused after the last LDS read
 
     const int tid = threadIdx.x;
@@ -313,8 +323,33 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * dv[i];
         taps_window<FW, VIF_SV, ORDER>(t, vo[4]);
     }
+    if (DFW > 0) {
+        // decimation, vertical pass at the even rows (y0 is even): source row y0 + 2*oy, columns x0-RD .. x0+TW+RD-1
+        for (int idx = tid; idx < 2 * (VIF_TH / 2) * DVW; idx += VIF_THREADS) {
+            const int pl = idx / ((VIF_TH / 2) * DVW), rem = idx - pl * ((VIF_TH / 2) * DVW);
+            const int oy = rem / DVW, c = rem - oy * DVW;
+            const float *src = (pl ? in_d : in_r) + (R - RD + 2 * oy) * IW + c + (G::HP - RD);
+            const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + 2 * oy, h, RD) && avx_vcol_ok(mirror_idx(x0 - RD + c, w), w);
+            dv_s[idx] = avx ? taps_avx_at<DFW ? DFW : 3, false>(src, IW) : taps_seq_at<DFW ? DFW : 3, false>(src, IW);
+        }
+    }
     __syncthreads();                                          // input tile fully consumed: alias it
     float *vout = smem;
+    if (DFW > 0) {
+        // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes
+        const int ow = w / 2, oh = h / 2, dend = avx_hcol_end(w, RD);
+        for (int idx = tid; idx < 2 * (VIF_TH / 2) * (VIF_TW / 2); idx += VIF_THREADS) {
+            const int pl = idx / ((VIF_TH / 2) * (VIF_TW / 2)), rem = idx - pl * ((VIF_TH / 2) * (VIF_TW / 2));
+            const int oy = rem / (VIF_TW / 2), ox = rem - oy * (VIF_TW / 2);
+            const float *src = dv_s + (pl * (VIF_TH / 2) + oy) * DVW + 2 * ox;
+            const int sx = x0 + 2 * ox;
+            const bool avx = ORDER == ORDER_AVX && sx >= RD && sx < dend;
+            const float val = avx ? taps_avx_at<DFW ? DFW : 3, false>(src, 1) : taps_seq_at<DFW ? DFW : 3, false>(src, 1);
+            const int gx = x0 / 2 + ox, gy = y0 / 2 + oy;
+            if (gx < ow && gy < oh)
+                (pl ? odis : oref)[(size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + gx] = val;
+        }
+    }
     if (vactive) {
 #pragma unroll
         for (int q = 0; q < 5; ++q)
@@ -442,50 +477,6 @@ __global__ __launch_bounds__(BD_THREADS) void vif_border_kernel(const float *__r
         }
     }
     block_reduce_store<2, BD_THREADS / 64>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2);
-}
-
-// ---------------------------------------------------------------- VIF pyramid step
-constexpr int DN_TW = 32, DN_TH = 16, DN_THREADS = 256;
-
-// vif.c:157-186: next = dec2(blur_{filter[scale+1]}(cur)); only the even samples are evaluated.
-template <int FW, bool OFFSET, int ORDER>
-__global__ __launch_bounds__(DN_THREADS) void vif_down_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
-                                                              size_t in_frame_stride, int in_row_stride, int w, int h,
-                                                              float *__restrict__ oref, float *__restrict__ odis,
-                                                              size_t out_frame_stride, int out_row_stride, int ow, int oh)
-{
-    constexpr int R = FW / 2, HP = (R + 3) / 4 * 4;
-    constexpr int IW = 2 * DN_TW + 2 * HP, IH = 2 * DN_TH + 2 * R;
-    __shared__ __attribute__((aligned(16))) float in_s[2][IH * IW];
-    __shared__ float v_s[2][DN_TH * IW];
-    const int tid = threadIdx.x;
-    const int ox0 = blockIdx.x * DN_TW, oy0 = blockIdx.y * DN_TH;
-    const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
-    const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
-
-    stage_tile<IH, IW, DN_THREADS, OFFSET, true>(fr, fd, in_row_stride, w, h, 2 * ox0 - HP, 2 * oy0 - R, in_s[0], in_s[1]);
-    __syncthreads();
-    for (int idx = tid; idx < 2 * DN_TH * IW; idx += DN_THREADS) {
-        const int pl = idx / (DN_TH * IW), rem = idx - pl * (DN_TH * IW);
-        const int oy = rem / IW, c = rem - oy * IW;
-        const float *src = &in_s[pl][(2 * oy) * IW + c];
-        const bool avx = ORDER == ORDER_AVX && avx_row_ok(2 * (oy0 + oy), h, R) && avx_vcol_ok(mirror_idx(2 * ox0 - HP + c, w), w);
-        v_s[pl][rem] = avx ? taps_avx_at<FW, false>(src, IW) : taps_seq_at<FW, false>(src, IW);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 2 * DN_TH * DN_TW; idx += DN_THREADS) {
-        const int pl = idx / (DN_TH * DN_TW), rem = idx - pl * (DN_TH * DN_TW);
-        const int oy = rem / DN_TW, ox = rem - oy * DN_TW;
-        const float *src = &v_s[pl][oy * IW + 2 * ox + (HP - R)];
-        const int sx = 2 * (ox0 + ox);                                  // source column of this output
-        const bool avx = ORDER == ORDER_AVX && sx >= R && sx < avx_hcol_end(w, R);
-        const float acc = avx ? taps_avx_at<FW, false>(src, 1) : taps_seq_at<FW, false>(src, 1);
-        const int gx = ox0 + ox, gy = oy0 + oy;
-        if (gx < ow && gy < oh) {
-            float *o = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + gx;
-            *o = acc;
-        }
-    }
 }
 
 // ---------------------------------------------------------------- ADM
@@ -636,36 +627,69 @@ __global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------- motion
-constexpr int MO_TW = 64, MO_TH = 16, MO_THREADS = 256;
+constexpr int MO_TW = 64, MO_TH = 24, MO_THREADS = 256;   // 1080 = 45 * 24: 1350 workgroups, one resident round on 256 CUs
 constexpr int MO_HP = 4;                                     // 2-pixel halo rounded up to a float4
 constexpr int MO_IW = MO_TW + 2 * MO_HP, MO_IH = MO_TH + 4;
+constexpr int MO_PER = MO_TH * MO_TW / MO_THREADS;           // outputs per thread
 
-// 5-tap blur of one tile of one raw ref plane into blur_out[MO_TH*MO_TW] (LDS), convolution.c:78-93 order (y then x)
-template <int ORDER>
-__device__ __forceinline__ void blur5_tile(const float *__restrict__ plane, int row_stride, int w, int h, int x0, int y0,
-                                           float *in_s, float *v_s, float *blur_out)
-{
-    const int tid = threadIdx.x;
-    stage_tile<MO_IH, MO_IW, MO_THREADS, true, false>(plane, nullptr, row_stride, w, h, x0 - MO_HP, y0 - 2, in_s, nullptr);
-    __syncthreads();
-    for (int idx = tid; idx < MO_TH * MO_IW; idx += MO_THREADS) {
-        const int oy = idx / MO_IW, c = idx - oy * MO_IW;
-        const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + oy, h, 2) && avx_vcol_ok(mirror_idx(x0 - MO_HP + c, w), w);
-        v_s[idx] = avx ? taps_avx_at<5, true>(&in_s[oy * MO_IW + c], MO_IW) : taps_seq_at<5, true>(&in_s[oy * MO_IW + c], MO_IW);
+// Register-staged copy of one ref window: load() only issues the global loads, store() writes them to LDS
+// (with the -128 offset), so the next frame's window is in flight while the current one is being filtered.
+struct MotionStage {
+    static constexpr int N4 = MO_IH * MO_IW / 4, IT4 = (N4 + MO_THREADS - 1) / MO_THREADS;
+    static constexpr int N1 = MO_IH * MO_IW, IT1 = (N1 + MO_THREADS - 1) / MO_THREADS;
+    float4 a4[IT4];
+    float a1[IT1];
+    __device__ __forceinline__ void load(const float *__restrict__ plane, int row_stride, int w, int h, int gx0, int gy0, bool fast)
+    {
+        const int tid = threadIdx.x;
+        if (fast) {
+#pragma unroll
+            for (int it = 0; it < IT4; ++it) {
+                const int idx = tid + it * MO_THREADS;
+                if (idx < N4) {
+                    const int ly = idx / (MO_IW / 4), l4 = idx - ly * (MO_IW / 4);
+                    a4[it] = *reinterpret_cast<const float4 *>(plane + (size_t)(gy0 + ly) * row_stride + gx0 + 4 * l4);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < IT1; ++it) {
+                const int idx = tid + it * MO_THREADS;
+                if (idx < N1) {
+                    const int ly = idx / MO_IW, lx = idx - ly * MO_IW;
+                    a1[it] = plane[(size_t)mirror_idx(gy0 + ly, h) * row_stride + mirror_idx(gx0 + lx, w)];
+                }
+            }
+        }
     }
-    __syncthreads();
-    for (int idx = tid; idx < MO_TH * MO_TW; idx += MO_THREADS) {
-        const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
-        const float *src = &v_s[oy * MO_IW + ox + (MO_HP - 2)];
-        const bool avx = ORDER == ORDER_AVX && x0 + ox >= 2 && x0 + ox < avx_hcol_end(w, 2);
-        blur_out[idx] = avx ? taps_avx_at<5, true>(src, 1) : taps_seq_at<5, true>(src, 1);
+    __device__ __forceinline__ void store(float *in_s, bool fast) const
+    {
+        const int tid = threadIdx.x;
+        if (fast) {
+#pragma unroll
+            for (int it = 0; it < IT4; ++it) {
+                const int idx = tid + it * MO_THREADS;
+                if (idx < N4) {
+                    float4 x = a4[it];
+                    x.x = x.x + -128.0f; x.y = x.y + -128.0f; x.z = x.z + -128.0f; x.w = x.w + -128.0f;   // combo.c:236
+                    *reinterpret_cast<float4 *>(in_s + 4 * idx) = x;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < IT1; ++it) {
+                const int idx = tid + it * MO_THREADS;
+                if (idx < N1) in_s[idx] = a1[it] + -128.0f;
+            }
+        }
     }
-    __syncthreads();
-}
+};
 
-// Motion of every frame of the batch (combo.c:309-326, motion.c:44-60).  Frame f > 0 re-blurs frame f-1
-// from the raw ref already in HBM; frame 0 reads the blurred plane carried over from the previous call.
-// The last frame's blurred tile is written to carry_out for the next call.
+// Motion of every frame of the batch (combo.c:309-326, motion.c:44-60).  One workgroup owns one 64x24 tile and
+// walks through the frames of the batch: 5-tap blur of the offset ref (convolution.c:78-93, y then x, in the
+// selected tap order), SAD against the previous frame's blurred tile, which stays in registers.  For frame 0
+// the previous tile comes from the plane carried over from the last call; the last frame's tile goes to
+// carry_out.  The blurred planes themselves never go to HBM.
 template <int ORDER>
 __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restrict__ ref, size_t frame_stride, int row_stride,
                                                             int w, int h, int nframes, int has_carry,
@@ -674,32 +698,55 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
 {
     __shared__ __attribute__((aligned(16))) float in_s[MO_IH * MO_IW];
     __shared__ float v_s[MO_TH * MO_IW];
-    __shared__ float cur_s[MO_TH * MO_TW];
-    __shared__ float prev_s[MO_TH * MO_TW];
     __shared__ double red[MO_THREADS / 64];
-    const int f = blockIdx.z;
     const int x0 = blockIdx.x * MO_TW, y0 = blockIdx.y * MO_TH;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
     const int tid = threadIdx.x;
+    const int gx0 = x0 - MO_HP, gy0 = y0 - 2;
+    const bool fast = gx0 >= 0 && gy0 >= 0 && gx0 + MO_IW <= w && gy0 + MO_IH <= h && ((gx0 | row_stride) & 3) == 0 &&
+                      (frame_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(ref) & 15) == 0;
+    const int hend = avx_hcol_end(w, 2);
 
-    blur5_tile<ORDER>(ref + (size_t)f * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, cur_s);
-    const bool have_prev = (f > 0) || has_carry;
-    if (f > 0) blur5_tile<ORDER>(ref + (size_t)(f - 1) * frame_stride, row_stride, w, h, x0, y0, in_s, v_s, prev_s);
-
-    double acc[1] = { 0.0 };
-    for (int idx = tid; idx < MO_TH * MO_TW; idx += MO_THREADS) {
-        const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
-        const int gx = x0 + ox, gy = y0 + oy;
-        if (gx < w && gy < h) {
-            const float c = cur_s[idx];
-            if (have_prev) {
-                const float p = (f > 0) ? prev_s[idx] : carry_in[(size_t)gy * w + gx];
-                acc[0] += (double)fabsf(p - c);
-            }
-            if (f == nframes - 1 && carry_out) carry_out[(size_t)gy * w + gx] = c;
+    float prev[MO_PER], cur[MO_PER];
+#pragma unroll
+    for (int k = 0; k < MO_PER; ++k) {
+        const int idx = tid + k * MO_THREADS;
+        const int gy = y0 + idx / MO_TW, gx = x0 + idx % MO_TW;
+        prev[k] = (has_carry && gx < w && gy < h) ? carry_in[(size_t)gy * w + gx] : 0.0f;
+    }
+    MotionStage st;
+    st.load(ref, row_stride, w, h, gx0, gy0, fast);
+    for (int f = 0; f < nframes; ++f) {
+        st.store(in_s, fast);
+        __syncthreads();
+        if (f + 1 < nframes) st.load(ref + (size_t)(f + 1) * frame_stride, row_stride, w, h, gx0, gy0, fast);
+        for (int idx = tid; idx < MO_TH * MO_IW; idx += MO_THREADS) {
+            const int oy = idx / MO_IW, c = idx - oy * MO_IW;
+            const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + oy, h, 2) && avx_vcol_ok(mirror_idx(gx0 + c, w), w);
+            v_s[idx] = avx ? taps_avx_at<5, true>(&in_s[oy * MO_IW + c], MO_IW) : taps_seq_at<5, true>(&in_s[oy * MO_IW + c], MO_IW);
+        }
+        __syncthreads();
+        double acc[1] = { 0.0 };
+#pragma unroll
+        for (int k = 0; k < MO_PER; ++k) {
+            const int idx = tid + k * MO_THREADS;
+            const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
+            const float *src = &v_s[oy * MO_IW + ox + (MO_HP - 2)];
+            const bool avx = ORDER == ORDER_AVX && x0 + ox >= 2 && x0 + ox < hend;
+            cur[k] = avx ? taps_avx_at<5, true>(src, 1) : taps_seq_at<5, true>(src, 1);
+            if ((f > 0 || has_carry) && x0 + ox < w && y0 + oy < h) acc[0] += (double)fabsf(prev[k] - cur[k]);
+            prev[k] = cur[k];
+        }
+        block_reduce_store<1, MO_THREADS / 64>(acc, red, partial + (size_t)f * ntiles + tile);
+    }
+    if (carry_out) {
+#pragma unroll
+        for (int k = 0; k < MO_PER; ++k) {
+            const int idx = tid + k * MO_THREADS;
+            const int gy = y0 + idx / MO_TW, gx = x0 + idx % MO_TW;
+            if (gx < w && gy < h) carry_out[(size_t)gy * w + gx] = cur[k];
         }
     }
-    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_reduce_store<1, MO_THREADS / 64>(acc, red, partial + tile);
 }
 
 // ---------------------------------------------------------------- final reduction
@@ -761,12 +808,13 @@ int vk_vif_border_tiles(int scale, int w, int h)
 }
 
 hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
-                              int w, int h, int nframes, double *partial, hipStream_t s)
+                              int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
+                              int out_row_stride, hipStream_t s)
 {
     const dim3 g = grid_for(w, h, VIF_TW, VIF_TH, nframes);
 #define VIF_STAT(FW, OFF)                                                                                                   \
-    if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); \
-    else vif_stat_kernel<FW, OFF, ORDER_AVX><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial)
+    if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride); \
+    else vif_stat_kernel<FW, OFF, ORDER_AVX><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride)
     switch (scale) {
     case 0: VIF_STAT(17, true); break;
     case 1: VIF_STAT(9, false); break;
@@ -791,25 +839,6 @@ hipError_t vk_launch_vif_border(int scale, const float *ref, const float *dis, s
     return hipGetLastError();
 }
 
-// to_scale in 1..3: input is scale to_scale-1 (w x h), output is (w/2) x (h/2)
-hipError_t vk_launch_vif_down(int to_scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
-                              int w, int h, float *oref, float *odis, size_t out_frame_stride, int out_row_stride,
-                              int nframes, hipStream_t s)
-{
-    const int ow = w / 2, oh = h / 2;
-    const dim3 g = grid_for(ow, oh, DN_TW, DN_TH, nframes);
-#define VIF_DOWN(FW, OFF)                                                                                                   \
-    if (order == ORDER_SCALAR) vif_down_kernel<FW, OFF, ORDER_SCALAR><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh); \
-    else vif_down_kernel<FW, OFF, ORDER_AVX><<<g, DN_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, oref, odis, out_frame_stride, out_row_stride, ow, oh)
-    switch (to_scale) {
-    case 1: VIF_DOWN(9, true); break;
-    case 2: VIF_DOWN(5, false); break;
-    default: VIF_DOWN(3, false); break;
-    }
-#undef VIF_DOWN
-    return hipGetLastError();
-}
-
 hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
@@ -829,7 +858,7 @@ hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, si
 hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
                             const float *carry_in, float *carry_out, double *partial, hipStream_t s)
 {
-    const dim3 g = grid_for(w, h, MO_TW, MO_TH, nframes);
+    const dim3 g = grid_for(w, h, MO_TW, MO_TH, 1);     // one workgroup per tile walks through the frames
     if (order == ORDER_SCALAR)
         motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
     else
