@@ -105,6 +105,18 @@ __device__ __forceinline__ int mirror_idx(int i, int n)
     return min(max(i, 0), n - 1);
 }
 
+// ---------------------------------------------------------------- XCD-aware tile order
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so blocks b and b+8 share an L2.
+// Tiles are numbered row-major; this bijection gives the blocks of one XCD a contiguous run of tiles, so the
+// halo rows/columns that neighbouring tiles have in common are fetched into that L2 once instead of once per
+// XCD.  Speed only - any placement is correct.  (grid.x = number of tiles, grid.z = frame)
+__device__ __forceinline__ int xcd_tile_index()
+{
+    const int b = blockIdx.x, nt = gridDim.x;
+    const int q = nt >> 3, r = nt & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 // ---------------------------------------------------------------- tile staging
 // Stage an IH x IW window (IW % 4 == 0) of one or two planes, whose top-left corner is image pixel
 // (gx0, gy0), into LDS (dense rows of IW floats).  Windows inside the image and 16-byte aligned take the
@@ -292,7 +304,9 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
     double *red = reinterpret_cast<double *>(smem);           // reused after the last LDS read
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * VIF_TW, y0 = blockIdx.y * VIF_TH;
+    const int ntx = (w + VIF_TW - 1) / VIF_TW;
+    const int tile_id = xcd_tile_index();
+    const int x0 = (tile_id % ntx) * VIF_TW, y0 = (tile_id / ntx) * VIF_TH;
     const float *fr = ref + (size_t)blockIdx.z * frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * frame_stride;
 
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
         }
     }
     __syncthreads();                                          // vout fully consumed: alias for the reduction
-    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t tile = (size_t)blockIdx.z * gridDim.x + tile_id;
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
 }
 
@@ -507,7 +521,9 @@ __global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__r
 
     const int tid = threadIdx.x;
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
-    const int cx0 = blockIdx.x * ADM_TW, cy0 = blockIdx.y * ADM_TH;   // first interior coefficient
+    const int ntx = (bw + ADM_TW - 1) / ADM_TW;
+    const int tile_id = xcd_tile_index();
+    const int cx0 = (tile_id % ntx) * ADM_TW, cy0 = (tile_id / ntx) * ADM_TH;   // first interior coefficient
     const int ix0 = 2 * cx0 - 4, iy0 = 2 * (cy0 - 1) - 1;            // first staged input pixel
     const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
@@ -622,7 +638,7 @@ __global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__r
         }
     }
     __syncthreads();
-    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t tile = (size_t)blockIdx.z * gridDim.x + tile_id;
     block_reduce_store<6, ADM_THREADS / 64>(acc, red, partial + tile * 6);
 }
 
@@ -787,6 +803,8 @@ __global__ __launch_bounds__(256) void svm_rbf_kernel(const double *__restrict__
 }
 
 inline dim3 grid_for(int w, int h, int tw, int th, int nframes) { return dim3((w + tw - 1) / tw, (h + th - 1) / th, nframes); }
+// tiles flattened into grid.x (XCD-aware order inside the kernel), frames in grid.z
+inline dim3 grid_flat(int w, int h, int tw, int th, int nframes) { return dim3(((w + tw - 1) / tw) * ((h + th - 1) / th), 1, nframes); }
 
 }  // namespace
 
@@ -811,7 +829,7 @@ hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const floa
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s)
 {
-    const dim3 g = grid_for(w, h, VIF_TW, VIF_TH, nframes);
+    const dim3 g = grid_flat(w, h, VIF_TW, VIF_TH, nframes);
 #define VIF_STAT(FW, OFF)                                                                                                   \
     if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride); \
     else vif_stat_kernel<FW, OFF, ORDER_AVX><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride)
@@ -845,7 +863,7 @@ hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, si
                                double *partial, hipStream_t s)
 {
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
-    const dim3 g = grid_for(bw, bh, ADM_TW, ADM_TH, nframes);
+    const dim3 g = grid_flat(bw, bh, ADM_TW, ADM_TH, nframes);
     if (scale == 0)
         adm_scale_kernel<true><<<g, ADM_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride,
                                                          ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial);
