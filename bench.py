@@ -41,7 +41,21 @@ FRAMES_PER_STEP = 30
 MODEL = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PATH_BYTES_PER_PX = 26.5        # algorithmic bytes of the whole path per luma pixel
-VIF0_BYTES_PER_PX = 8.0         # dominant kernel: reads the fp32 ref and dis planes once
+VIF0_BYTES_PER_PX = 10.0        # dominant kernel: reads the fp32 ref and dis planes once (8 B/px) and writes the
+                                # two decimated planes of the next VIF scale (2 x 4 B / 4 px = 2 B/px)
+
+
+def measured_traffic(frames_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json, written
+    by tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this bench;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile matches."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if (t["width"], t["height"]) != (W, H):
+            return None
+        return int(t["hbm_bytes_per_launch"] * frames_per_launch / t["frames_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(ref, dis, budget_s=20.0, max_frames=64):
@@ -130,7 +144,8 @@ def main():
         if kernel_ms:
             achieved = VIF0_BYTES_PER_PX * W * H * B / (kernel_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "vif_stat_kernel<17> (VIF scale 0, fused)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(B),
+                    "algorithmic_bytes": int(VIF0_BYTES_PER_PX * W * H * B),
                     "launch_ms": round(kernel_ms, 4), "frames_per_launch": B,
                     "path_achieved_gbs": round(PATH_BYTES_PER_PX * W * H * fps / world / 1e9, 1)}
         line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/<tag>/) into the tracked summaries:
+
+    profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python bench.py` (verbatim)
+    profiles/<tag>_hbm_traffic.csv    per kernel: FETCH_SIZE, WRITE_SIZE per launch (KB as reported) and the
+                                      corrected bytes (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md "HBM")
+    profiles/<tag>_bench.json         the bench line of the same build
+    profiles/traffic.json             what bench.py reads for roofline.traffic (dominant kernel, bytes/launch)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?|__amd_rocclr_\w+)", name)
+    return m.group(1) if m else name[:40]
+
+
+def counters(path, counter):
+    files = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    bench = os.path.join(src, "bench.json")
+    frames = 30
+    if os.path.exists(bench):
+        lines = [l for l in open(bench) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_bench.json"), "w").write(lines[-1])
+            frames = json.loads(lines[-1])["roofline"]["frames_per_launch"]
+    fetch = counters(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    write = counters(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write), key=lambda k: -fetch.get(k, (0, 0))[0]):
+        f, n = fetch.get(k, (0.0, 0))
+        w, _ = write.get(k, (0.0, 0))
+        rows.append({"kernel": k, "launches_sampled": n, "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+                     "read_bytes_corrected": int(2 * f * 1024), "write_bytes": int(w * 1024),
+                     "hbm_bytes_per_launch": int((2 * f + w) * 1024)})
+    if rows:
+        with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w", newline="") as fh:
+            wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
+            wr.writeheader()
+            wr.writerows(rows)
+        dom = next((r for r in rows if r["kernel"].startswith("vif_stat_kernel<17")), None)
+        if dom:
+            json.dump({"source": f"profiles/{tag}_hbm_traffic.csv", "kernel": dom["kernel"], "frames_per_launch": frames,
+                       "width": 1920, "height": 1080, "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],
+                       "note": "FETCH_SIZE (KB) x2 [gfx950 correction] + WRITE_SIZE (KB), separate --pmc passes"},
+                      open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print("wrote", sorted(os.listdir(dst)))
+
+
+if __name__ == "__main__":
+    main()
