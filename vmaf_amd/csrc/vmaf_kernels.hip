@@ -494,144 +494,207 @@ __global__ __launch_bounds__(BD_THREADS) void vif_border_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------- ADM
-constexpr int ADM_TW = 32, ADM_TH = 16, ADM_THREADS = 256;
-constexpr int ADM_SW = ADM_TW + 2, ADM_SH = ADM_TH + 2;      // coefficient slots incl. 1-px halo
-constexpr int ADM_IW = 2 * ADM_SW + 4, ADM_IH = 2 * ADM_SH + 2;  // staged input: columns from 2*cx0-4 (float4 aligned), rows from 2*cy0-3
-constexpr int ADM_SLOTS = ADM_SW * ADM_SH;
-constexpr int ADM_ITEMS = (ADM_SLOTS + ADM_THREADS - 1) / ADM_THREADS;
+// One workgroup = ADM_SW x ADM_SH coefficient slots (a ADM_TW x ADM_TH interior plus the one-coefficient halo the
+// masking threshold looks at), 256 threads, no staging of the input picture:
+//   phase 1  vertical db2 pass straight from global memory: thread = one input column x half of the slot rows,
+//            its 18 input rows are all in flight before the first use; the four vertical sums of a (slot row,
+//            column) go to LDS as one float4, columns split into an even and an odd plane so that
+//   phase 2  the horizontal pass of slot tx reads float4s [tx] and [tx+1] of both planes (conflict free);
+//            thread = slot column x 4 slot rows; decouple + CSF stay in registers, (1/30)|csf_a| goes to LDS
+//   phase 3  threshold from the 3x3 neighbourhood, contrast masking, cube sums.
+constexpr int ADM_THREADS = 256;
+constexpr int ADM_SW = 63, ADM_SH = 16;                        // slots: 2*63+2 = 128 input columns = two waves of lanes
+constexpr int ADM_TW = ADM_SW - 2, ADM_TH = ADM_SH - 2;        // interior coefficients per workgroup
+constexpr int ADM_COLS = 2 * ADM_SW + 2;                       // 128
+constexpr int ADM_RPT = ADM_SH / 2;                            // slot rows per thread in phase 1 (8)
+constexpr int ADM_SPT = ADM_SH / 4;                            // slots per thread in phases 2 and 3 (4)
+constexpr int ADM_VP = 72;                                     // float4s per (slot row, parity) plane: 64 + 8 so that the two
+                                                               // parities of a 16-lane group fall into different banks
+constexpr int ADM_AW = 64;                                     // row pitch of the |csf_a| planes
+static_assert(ADM_COLS == 128 && ADM_THREADS == 2 * ADM_COLS, "phase 1 maps thread -> (column, row half)");
 
 // One ADM scale, fused (adm.c:132-247 for one value of `scale`): adm_dwt2 x2, adm_decouple, adm_csf x3,
 // adm_cm_thresh, adm_cm and the six adm_sum_cube accumulations.  Only the LL bands go back to HBM.
 template <bool OFFSET>
-__global__ __launch_bounds__(ADM_THREADS) void adm_scale_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
-                                                                size_t in_frame_stride, int in_row_stride, int w, int h,
-                                                                float *__restrict__ ll_ref, float *__restrict__ ll_dis,
-                                                                size_t ll_frame_stride, int ll_row_stride,
-                                                                float rfac_hv, float rfac_d,
-                                                                int left, int top, int right, int bottom,
-                                                                double *__restrict__ partial)
+__global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                                   size_t in_frame_stride, int in_row_stride, int w, int h,
+                                                                   float *__restrict__ ll_ref, float *__restrict__ ll_dis,
+                                                                   size_t ll_frame_stride, int ll_row_stride,
+                                                                   float rfac_hv, float rfac_d,
+                                                                   int left, int top, int right, int bottom,
+                                                                   double *__restrict__ partial)
 {
-    constexpr int IN_F = ADM_IH * ADM_IW;                     // per plane
-    constexpr int V_F = ADM_SH * ADM_IW;                      // per vertical-pass plane
-    __shared__ __attribute__((aligned(16))) float smem[2 * IN_F + 4 * V_F + 3 * ADM_SLOTS];
-    float *in_r = smem, *in_d = smem + IN_F;
-    float *vlo_r = smem + 2 * IN_F, *vhi_r = vlo_r + V_F, *vlo_d = vhi_r + V_F, *vhi_d = vlo_d + V_F;
-    float *absa = vhi_d + V_F;                                // |csf_a| for h, v, d: [3][ADM_SLOTS]
-    double *red = reinterpret_cast<double *>(smem);
+    __shared__ float4 vbuf[ADM_SH * 2 * ADM_VP];               // [slot row][column parity][column / 2] = {lo_r, hi_r, lo_d, hi_d}
+    float *absa = reinterpret_cast<float *>(vbuf);             // after phase 2: (1/30)|csf_a|, [band h,v,d][ADM_SH][ADM_AW]
+    double *red = reinterpret_cast<double *>(vbuf);
 
     const int tid = threadIdx.x;
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     const int ntx = (bw + ADM_TW - 1) / ADM_TW;
     const int tile_id = xcd_tile_index();
     const int cx0 = (tile_id % ntx) * ADM_TW, cy0 = (tile_id / ntx) * ADM_TH;   // first interior coefficient
-    const int ix0 = 2 * cx0 - 4, iy0 = 2 * (cy0 - 1) - 1;            // first staged input pixel
     const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
 
-    stage_tile<ADM_IH, ADM_IW, ADM_THREADS, OFFSET, true>(fr, fd, in_row_stride, w, h, ix0, iy0, in_r, in_d);
-    __syncthreads();
-
-    // vertical db2 pass at the (mirrored) coefficient rows of every slot row, all staged columns
-    for (int idx = tid; idx < V_F; idx += ADM_THREADS) {
-        const int ty = idx / ADM_IW, lx = idx - ty * ADM_IW;
-        const int cy = mirror_idx(cy0 - 1 + ty, bh);                  // adm_tools.c:241-244 (threshold halo)
-        const int lr = min(max(2 * (cy - (cy0 - 1)), 0), ADM_IH - 4);     // staged row of tap 0 (= pixel 2cy-1)
-        float lo_r = 0.0f, hi_r = 0.0f, lo_d = 0.0f, hi_d = 0.0f;
+    // ---- phase 1: vertical pass (adm_tools.c:313-334), taps of coefficient row cy at pixel rows 2cy-1 .. 2cy+2
+    {
+        const int l = tid & (ADM_COLS - 1);
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 7);                // wave-uniform
+        const int xc = mirror_idx(2 * cx0 - 3 + l, w);                            // slot 0 = coefficient cx0-1, tap 0 = pixel 2(cx0-1)-1
+        const int ty0 = half * ADM_RPT;
+        const int iy0 = 2 * (cy0 - 1 + ty0) - 1;
+        float pr[2 * ADM_RPT + 2], pd[2 * ADM_RPT + 2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float pr = in_r[(lr + t) * ADM_IW + lx], pd = in_d[(lr + t) * ADM_IW + lx];
-            lo_r = lo_r + kDb2Lo[t] * pr;
-            hi_r = hi_r + kDb2Hi[t] * pr;
-            lo_d = lo_d + kDb2Lo[t] * pd;
-            hi_d = hi_d + kDb2Hi[t] * pd;
+        for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
+            const size_t g = (size_t)mirror_idx(iy0 + k, h) * in_row_stride + xc;
+            pr[k] = fr[g];
+            pd[k] = fd[g];
         }
-        vlo_r[idx] = lo_r; vhi_r[idx] = hi_r; vlo_d[idx] = lo_d; vhi_d[idx] = hi_d;
+        if (OFFSET) {
+#pragma unroll
+            for (int k = 0; k < 2 * ADM_RPT + 2; ++k) { pr[k] = pr[k] + -128.0f; pd[k] = pd[k] + -128.0f; }   // offset_image, combo.c:236-237
+        }
+        float4 *vdst = vbuf + (ty0 * 2 + (l & 1)) * ADM_VP + (l >> 1);
+#pragma unroll
+        for (int i = 0; i < ADM_RPT; ++i) {
+            // sums start from the first product: 0.0f + x == x except for the sign of a zero, which nothing downstream sees
+            float lo_r = kDb2Lo[0] * pr[2 * i], hi_r = kDb2Hi[0] * pr[2 * i];
+            float lo_d = kDb2Lo[0] * pd[2 * i], hi_d = kDb2Hi[0] * pd[2 * i];
+#pragma unroll
+            for (int t = 1; t < 4; ++t) {
+                lo_r = lo_r + kDb2Lo[t] * pr[2 * i + t];
+                hi_r = hi_r + kDb2Hi[t] * pr[2 * i + t];
+                lo_d = lo_d + kDb2Lo[t] * pd[2 * i + t];
+                hi_d = hi_d + kDb2Hi[t] * pd[2 * i + t];
+            }
+            vdst[i * 2 * ADM_VP] = make_float4(lo_r, hi_r, lo_d, hi_d);
+        }
     }
     __syncthreads();
 
-    // horizontal db2 pass + decouple + CSF for every slot
-    float keep_r[ADM_ITEMS][3], keep_o[ADM_ITEMS][3];
+    // ---- phase 2: horizontal pass + decouple + CSF; thread = slot column tx, slot rows 4*wave .. 4*wave+3
+    const int tx = tid & 63, wv = tid >> 6;
+    const bool lane_on = tx < ADM_SW;
+    const int cxr = cx0 - 1 + tx;
+    float keep_r[ADM_SPT][3], keep_o[ADM_SPT][3], p30[ADM_SPT][3], p15[ADM_SPT][3];
     const float cos1sq = (float)(0.99984769515639127 * 0.99984769515639127);   // cos(1 deg)^2, adm_tools.c:82
 #pragma unroll
-    for (int it = 0; it < ADM_ITEMS; ++it) {
-        const int idx = tid + it * ADM_THREADS;
-        if (idx < ADM_SLOTS) {
-            const int ty = idx / ADM_SW, tx = idx - ty * ADM_SW;
-            const int cxr = cx0 - 1 + tx, cyr = cy0 - 1 + ty;
-            const int cx = mirror_idx(cxr, bw);
-            const int lc = min(max(2 * (cx - cx0) + 3, 0), ADM_IW - 4);  // staged column of tap 0 (= pixel 2cx-1)
-            float ra = 0.0f, rv = 0.0f, rh = 0.0f, rd = 0.0f, da = 0.0f, dv = 0.0f, dh = 0.0f, dd = 0.0f;
+    for (int s = 0; s < ADM_SPT; ++s) {
+        const int ty = wv * ADM_SPT + s;
+        const int cyr = cy0 - 1 + ty;
+        const int txc = lane_on ? tx : 0;
+        const float4 *row = vbuf + ty * 2 * ADM_VP;
+        const float4 q[4] = { row[txc], row[ADM_VP + txc], row[txc + 1], row[ADM_VP + txc + 1] };   // pixel columns 2cx-1 .. 2cx+2
+        float ra = kDb2Lo[0] * q[0].x, rv = kDb2Hi[0] * q[0].x;       // band_a, band_v (adm_tools.c:336-361)
+        float rh = kDb2Lo[0] * q[0].y, rd = kDb2Hi[0] * q[0].y;       // band_h, band_d (adm_tools.c:363-388)
+        float da = kDb2Lo[0] * q[0].z, dv = kDb2Hi[0] * q[0].z;
+        float dh = kDb2Lo[0] * q[0].w, dd = kDb2Hi[0] * q[0].w;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int o = ty * ADM_IW + lc + t;
-                const float lr = vlo_r[o], hr = vhi_r[o], ld = vlo_d[o], hd = vhi_d[o];
-                ra = ra + kDb2Lo[t] * lr;   rv = rv + kDb2Hi[t] * lr;     // band_a, band_v (adm_tools.c:336-361)
-                rh = rh + kDb2Lo[t] * hr;   rd = rd + kDb2Hi[t] * hr;     // band_h, band_d (adm_tools.c:363-388)
-                da = da + kDb2Lo[t] * ld;   dv = dv + kDb2Hi[t] * ld;
-                dh = dh + kDb2Lo[t] * hd;   dd = dd + kDb2Hi[t] * hd;
-            }
-            const bool interior = tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH && cxr < bw && cyr < bh;
-            if (interior && ll_ref) {
-                const size_t g = (size_t)blockIdx.z * ll_frame_stride + (size_t)cyr * ll_row_stride + cxr;
-                ll_ref[g] = ra;
-                ll_dis[g] = da;
-            }
-            // adm_decouple (adm_tools.c:101-173), band order h, v, d
-            const float o3[3] = { rh, rv, rd }, t3[3] = { dh, dv, dd };
-            float rest[3];
+        for (int t = 1; t < 4; ++t) {
+            ra = ra + kDb2Lo[t] * q[t].x;   rv = rv + kDb2Hi[t] * q[t].x;
+            rh = rh + kDb2Lo[t] * q[t].y;   rd = rd + kDb2Hi[t] * q[t].y;
+            da = da + kDb2Lo[t] * q[t].z;   dv = dv + kDb2Hi[t] * q[t].z;
+            dh = dh + kDb2Lo[t] * q[t].w;   dd = dd + kDb2Hi[t] * q[t].w;
+        }
+        const bool interior = lane_on && tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH && cxr < bw && cyr < bh;
+        if (interior && ll_ref) {
+            const size_t g = (size_t)blockIdx.z * ll_frame_stride + (size_t)cyr * ll_row_stride + cxr;
+            ll_ref[g] = ra;
+            ll_dis[g] = da;
+        }
+        // adm_decouple (adm_tools.c:101-173), band order h, v, d
+        const float o3[3] = { rh, rv, rd }, t3[3] = { dh, dv, dd };
+        float rest[3];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float k = t3[b] / (o3[b] + 1e-30f);
-                k = k < 0.0f ? 0.0f : (k > 1.0f ? 1.0f : k);
-                rest[b] = k * o3[b];
-            }
-            const float dp = rh * dh + rv * dv;
-            const float om = rh * rh + rv * rv;
-            const float tm = dh * dh + dv * dv;
-            const bool aligned = (dp >= 0.0f) && (dp * dp >= cos1sq * om * tm);
+        for (int b = 0; b < 3; ++b) {
+            float k = t3[b] / (o3[b] + 1e-30f);
+            k = k < 0.0f ? 0.0f : (k > 1.0f ? 1.0f : k);
+            rest[b] = k * o3[b];
+        }
+        const float dp = rh * dh + rv * dv;
+        const float om = rh * rh + rv * rv;
+        const float tm = dh * dh + dv * dv;
+        const bool aligned = (dp >= 0.0f) && (dp * dp >= cos1sq * om * tm);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const float rf = (b == 2) ? rfac_d : rfac_hv;                 // adm_csf, adm_tools.c:190-202
-                const float r = aligned ? t3[b] : rest[b];
-                const float a = t3[b] - r;
-                keep_o[it][b] = rf * o3[b];
-                keep_r[it][b] = rf * r;
-                absa[b * ADM_SLOTS + idx] = fabsf(rf * a);
-            }
+        for (int b = 0; b < 3; ++b) {
+            const float rf = (b == 2) ? rfac_d : rfac_hv;                 // adm_csf, adm_tools.c:190-202
+            const float r = aligned ? t3[b] : rest[b];
+            const float a = t3[b] - r;
+            keep_o[s][b] = rf * o3[b];
+            keep_r[s][b] = rf * r;
+            const float aa = fabsf(rf * a);
+            p30[s][b] = (1.0f / 30.0f) * aa;                              // adm_cm_thresh's weight of a neighbour (to LDS)
+            p15[s][b] = (1.0f / 15.0f) * aa;                              // and of the centre (stays here)
+        }
+    }
+    __syncthreads();                                                      // every float4 of vbuf has been read
+
+    // (1/30)|csf_a| planes; slots on the image edge also fill the halo slots that mirror onto them
+    // (adm_tools.c:241-248: -1 -> 1, n -> n-1), so that phase 3 indexes its 3x3 window blindly
+    if (lane_on && cxr >= 0 && cxr < bw) {                               // slots outside the image own nothing
+        const int cols[3] = { tx, (cxr == 1 && tx == 2) ? 0 : -1, (cxr == bw - 1 && tx + 1 < ADM_AW) ? tx + 1 : -1 };
+#pragma unroll
+        for (int s = 0; s < ADM_SPT; ++s) {
+            const int ty = wv * ADM_SPT + s;
+            const int cyr = cy0 - 1 + ty;
+            const bool real = cyr >= 0 && cyr < bh;
+            const int rows[3] = { real ? ty : -1, (cyr == 1 && ty == 2) ? 0 : -1, (cyr == bh - 1 && ty + 1 < ADM_SH) ? ty + 1 : -1 };
+#pragma unroll
+            for (int ri = 0; ri < 3; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+                    if (rows[ri] >= 0 && cols[ci] >= 0) {
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) absa[(b * ADM_SH + rows[ri]) * ADM_AW + cols[ci]] = p30[s][b];
+                    }
         }
     }
     __syncthreads();
 
-    // masking threshold, contrast masking and cube sums for the interior slots
+    // ---- phase 3: masking threshold, contrast masking and cube sums for the interior slots
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    {
+        const int r0 = wv * ADM_SPT - 1;                                  // first neighbour row of this thread's slots
+        const int xl = max(tx - 1, 0), xr = min(tx + 1, ADM_AW - 1);
+        float thr[ADM_SPT];
 #pragma unroll
-    for (int it = 0; it < ADM_ITEMS; ++it) {
-        const int idx = tid + it * ADM_THREADS;
-        if (idx < ADM_SLOTS) {
-            const int ty = idx / ADM_SW, tx = idx - ty * ADM_SW;
-            const int cxr = cx0 - 1 + tx, cyr = cy0 - 1 + ty;
+        for (int b = 0; b < 3; ++b) {
+            const float *pl = absa + b * ADM_SH * ADM_AW;
+            float nb[ADM_SPT + 2][3];
+#pragma unroll
+            for (int r = 0; r < ADM_SPT + 2; ++r) {
+                const int rr = min(max(r0 + r, 0), ADM_SH - 1);           // clamped rows belong to halo slots only
+                nb[r][0] = pl[rr * ADM_AW + xl];
+                nb[r][1] = pl[rr * ADM_AW + tx];
+                nb[r][2] = pl[rr * ADM_AW + xr];
+            }
+#pragma unroll
+            for (int s = 0; s < ADM_SPT; ++s) {                           // adm_cm_thresh, adm_tools.c:220-257, same order of additions
+                float a = nb[s][0];
+                a = a + nb[s][1];
+                a = a + nb[s][2];
+                a = a + nb[s + 1][0];
+                a = a + p15[s][b];
+                a = a + nb[s + 1][2];
+                a = a + nb[s + 2][0];
+                a = a + nb[s + 2][1];
+                a = a + nb[s + 2][2];
+                thr[s] = b == 0 ? a : thr[s] + a;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < ADM_SPT; ++s) {
+            const int ty = wv * ADM_SPT + s;
+            const int cyr = cy0 - 1 + ty;
             const bool inwin = tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH &&
                                cxr >= left && cxr < right && cyr >= top && cyr < bottom;
             if (inwin) {
-                float thr = 0.0f;                                             // adm_cm_thresh, adm_tools.c:220-257
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
-                    float a = 0.0f;
-#pragma unroll
-                    for (int di = -1; di <= 1; ++di)
-#pragma unroll
-                        for (int dj = -1; dj <= 1; ++dj) {
-                            const float c = (di == 0 && dj == 0) ? 1.0f / 15.0f : 1.0f / 30.0f;
-                            a = a + c * absa[b * ADM_SLOTS + (ty + di) * ADM_SW + tx + dj];
-                        }
-                    thr = thr + a;
-                }
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    float x = fabsf(keep_r[it][b]) - thr;                     // adm_cm, adm_tools.c:278-284
+                    float x = fabsf(keep_r[s][b]) - thr[s];               // adm_cm, adm_tools.c:278-284
                     x = x < 0.0f ? 0.0f : x;
-                    acc[b] += (double)(x * x * x);                            // adm_sum_cube, adm_tools.c:68-70
-                    const float y = fabsf(keep_o[it][b]);
+                    acc[b] += (double)(x * x * x);                        // adm_sum_cube, adm_tools.c:68-70
+                    const float y = fabsf(keep_o[s][b]);
                     acc[3 + b] += (double)(y * y * y);
                 }
             }
