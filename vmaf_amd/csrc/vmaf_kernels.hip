@@ -24,6 +24,7 @@
 //   svm_rbf_kernel        batched nu-SVR RBF prediction
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "vmaf_kernels.h"
 
 namespace {
@@ -706,124 +707,120 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
 }
 
 // ---------------------------------------------------------------- motion
-constexpr int MO_TW = 64, MO_TH = 24, MO_THREADS = 256;   // 1080 = 45 * 24: 1350 workgroups, one resident round on 256 CUs
-constexpr int MO_HP = 4;                                     // 2-pixel halo rounded up to a float4
-constexpr int MO_IW = MO_TW + 2 * MO_HP, MO_IH = MO_TH + 4;
-constexpr int MO_PER = MO_TH * MO_TW / MO_THREADS;           // outputs per thread
+// One workgroup owns a 60x32 tile and walks through a chunk of consecutive frames (combo.c:309-326,
+// motion.c:44-60): 5-tap blur of the offset ref (convolution.c:78-93, y then x, in the selected tap order),
+// SAD against the previous frame's blurred tile, which stays in registers.  No staging of the picture:
+//   vertical pass    thread = one of the 64 staged columns (60 + 2x2 halo = one wave) x 8 rows; its 12 input
+//                    rows of the NEXT frame are in flight while the current frame is being filtered
+//   horizontal pass  thread = 8 consecutive outputs of one row, read from LDS as three float4
+// The chunk's first workgroup-iteration only rebuilds the blur of the frame before the chunk (chunk 0 takes it
+// from the plane carried over from the previous call); the last frame's tile goes to carry_out.
+// The blurred planes themselves never go to HBM.  One __syncthreads per frame (double-buffered LDS);
+// every wave stores its own SAD partial, so there is no block reduction either.
+constexpr int MO_TW = 60, MO_TH = 32, MO_THREADS = 256;
+constexpr int MO_CW = MO_TW + 4;                             // staged columns x0-2 .. x0+61
+constexpr int MO_RPT = MO_TH / (MO_THREADS / 64);            // rows per thread, vertical pass (8)
+constexpr int MO_OPT = 8;                                    // outputs per thread, horizontal pass
+constexpr int MO_VP = MO_CW + 4;                             // LDS row pitch: successive rows start 4 banks apart
+constexpr int MO_WAVES = MO_THREADS / 64;
+static_assert(MO_CW == 64 && MO_TH * (MO_CW / MO_OPT) == MO_THREADS, "thread maps");
 
-// Register-staged copy of one ref window: load() only issues the global loads, store() writes them to LDS
-// (with the -128 offset), so the next frame's window is in flight while the current one is being filtered.
-struct MotionStage {
-    static constexpr int N4 = MO_IH * MO_IW / 4, IT4 = (N4 + MO_THREADS - 1) / MO_THREADS;
-    static constexpr int N1 = MO_IH * MO_IW, IT1 = (N1 + MO_THREADS - 1) / MO_THREADS;
-    float4 a4[IT4];
-    float a1[IT1];
-    __device__ __forceinline__ void load(const float *__restrict__ plane, int row_stride, int w, int h, int gx0, int gy0, bool fast)
-    {
-        const int tid = threadIdx.x;
-        if (fast) {
-#pragma unroll
-            for (int it = 0; it < IT4; ++it) {
-                const int idx = tid + it * MO_THREADS;
-                if (idx < N4) {
-                    const int ly = idx / (MO_IW / 4), l4 = idx - ly * (MO_IW / 4);
-                    a4[it] = *reinterpret_cast<const float4 *>(plane + (size_t)(gy0 + ly) * row_stride + gx0 + 4 * l4);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < IT1; ++it) {
-                const int idx = tid + it * MO_THREADS;
-                if (idx < N1) {
-                    const int ly = idx / MO_IW, lx = idx - ly * MO_IW;
-                    a1[it] = plane[(size_t)mirror_idx(gy0 + ly, h) * row_stride + mirror_idx(gx0 + lx, w)];
-                }
-            }
-        }
-    }
-    __device__ __forceinline__ void store(float *in_s, bool fast) const
-    {
-        const int tid = threadIdx.x;
-        if (fast) {
-#pragma unroll
-            for (int it = 0; it < IT4; ++it) {
-                const int idx = tid + it * MO_THREADS;
-                if (idx < N4) {
-                    float4 x = a4[it];
-                    x.x = x.x + -128.0f; x.y = x.y + -128.0f; x.z = x.z + -128.0f; x.w = x.w + -128.0f;   // combo.c:236
-                    *reinterpret_cast<float4 *>(in_s + 4 * idx) = x;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < IT1; ++it) {
-                const int idx = tid + it * MO_THREADS;
-                if (idx < N1) in_s[idx] = a1[it] + -128.0f;
-            }
-        }
-    }
-};
+template <int ORDER> __device__ __forceinline__ float motion_taps(const float *v, bool avx)
+{
+    if (ORDER == ORDER_SCALAR) return taps_seq_at<5, true>(v, 1);
+    // wave-uniform branches: a wave evaluates an order only if one of its lanes needs it
+    float ra = 0.0f, rs = 0.0f;
+    if (__any(avx)) ra = taps_avx_at<5, true>(v, 1);
+    if (__any(!avx)) rs = taps_seq_at<5, true>(v, 1);
+    return avx ? ra : rs;
+}
 
-// Motion of every frame of the batch (combo.c:309-326, motion.c:44-60).  One workgroup owns one 64x24 tile and
-// walks through the frames of the batch: 5-tap blur of the offset ref (convolution.c:78-93, y then x, in the
-// selected tap order), SAD against the previous frame's blurred tile, which stays in registers.  For frame 0
-// the previous tile comes from the plane carried over from the last call; the last frame's tile goes to
-// carry_out.  The blurred planes themselves never go to HBM.
 template <int ORDER>
 __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restrict__ ref, size_t frame_stride, int row_stride,
-                                                            int w, int h, int nframes, int has_carry,
+                                                            int w, int h, int nframes, int chunk, int has_carry,
                                                             const float *__restrict__ carry_in, float *__restrict__ carry_out,
                                                             double *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) float in_s[MO_IH * MO_IW];
-    __shared__ float v_s[MO_TH * MO_IW];
-    __shared__ double red[MO_THREADS / 64];
-    const int x0 = blockIdx.x * MO_TW, y0 = blockIdx.y * MO_TH;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
-    const int tid = threadIdx.x;
-    const int gx0 = x0 - MO_HP, gy0 = y0 - 2;
-    const bool fast = gx0 >= 0 && gy0 >= 0 && gx0 + MO_IW <= w && gy0 + MO_IH <= h && ((gx0 | row_stride) & 3) == 0 &&
-                      (frame_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(ref) & 15) == 0;
+    __shared__ __attribute__((aligned(16))) float v_s[2][MO_TH * MO_VP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntx = (w + MO_TW - 1) / MO_TW;
+    const int tile = blockIdx.x, ntiles = gridDim.x;
+    const int x0 = (tile % ntx) * MO_TW, y0 = (tile / ntx) * MO_TH;
+    const int f_begin = blockIdx.y * chunk, f_end = min(nframes, f_begin + chunk);
+
+    // vertical-pass identity
+    const int xc = mirror_idx(x0 - 2 + lane, w);
+    const int vy0 = y0 + wv * MO_RPT;                                 // first output row of this wave
+    const bool vcol_avx = ORDER == ORDER_AVX && avx_vcol_ok(xc, w);
+    int roff[MO_RPT + 4];                                             // one plane holds < 2^31 floats (engine limit)
+#pragma unroll
+    for (int k = 0; k < MO_RPT + 4; ++k) roff[k] = mirror_idx(vy0 - 2 + k, h) * row_stride;
+    // horizontal-pass identity
+    const int hr = tid >> 3, ox0 = (tid & 7) * MO_OPT;
+    const int gy = y0 + hr;
     const int hend = avx_hcol_end(w, 2);
 
-    float prev[MO_PER], cur[MO_PER];
+    float prev[MO_OPT], cur[MO_OPT], in[MO_RPT + 4];
+    int f = f_begin;
+    if (f_begin == 0) {
 #pragma unroll
-    for (int k = 0; k < MO_PER; ++k) {
-        const int idx = tid + k * MO_THREADS;
-        const int gy = y0 + idx / MO_TW, gx = x0 + idx % MO_TW;
-        prev[k] = (has_carry && gx < w && gy < h) ? carry_in[(size_t)gy * w + gx] : 0.0f;
-    }
-    MotionStage st;
-    st.load(ref, row_stride, w, h, gx0, gy0, fast);
-    for (int f = 0; f < nframes; ++f) {
-        st.store(in_s, fast);
-        __syncthreads();
-        if (f + 1 < nframes) st.load(ref + (size_t)(f + 1) * frame_stride, row_stride, w, h, gx0, gy0, fast);
-        for (int idx = tid; idx < MO_TH * MO_IW; idx += MO_THREADS) {
-            const int oy = idx / MO_IW, c = idx - oy * MO_IW;
-            const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + oy, h, 2) && avx_vcol_ok(mirror_idx(gx0 + c, w), w);
-            v_s[idx] = avx ? taps_avx_at<5, true>(&in_s[oy * MO_IW + c], MO_IW) : taps_seq_at<5, true>(&in_s[oy * MO_IW + c], MO_IW);
+        for (int j = 0; j < MO_OPT; ++j) {
+            const int gx = x0 + ox0 + j;
+            prev[j] = (has_carry && ox0 + j < MO_TW && gx < w && gy < h) ? carry_in[(size_t)gy * w + gx] : 0.0f;
         }
-        __syncthreads();
-        double acc[1] = { 0.0 };
+    } else {
+        f = f_begin - 1;                                              // warm-up iteration: blur only
 #pragma unroll
-        for (int k = 0; k < MO_PER; ++k) {
-            const int idx = tid + k * MO_THREADS;
-            const int oy = idx / MO_TW, ox = idx - oy * MO_TW;
-            const float *src = &v_s[oy * MO_IW + ox + (MO_HP - 2)];
-            const bool avx = ORDER == ORDER_AVX && x0 + ox >= 2 && x0 + ox < hend;
-            cur[k] = avx ? taps_avx_at<5, true>(src, 1) : taps_seq_at<5, true>(src, 1);
-            if ((f > 0 || has_carry) && x0 + ox < w && y0 + oy < h) acc[0] += (double)fabsf(prev[k] - cur[k]);
-            prev[k] = cur[k];
-        }
-        block_reduce_store<1, MO_THREADS / 64>(acc, red, partial + (size_t)f * ntiles + tile);
+        for (int j = 0; j < MO_OPT; ++j) prev[j] = 0.0f;
     }
-    if (carry_out) {
+    {
+        const float *p = ref + (size_t)f * frame_stride + xc;
 #pragma unroll
-        for (int k = 0; k < MO_PER; ++k) {
-            const int idx = tid + k * MO_THREADS;
-            const int gy = y0 + idx / MO_TW, gx = x0 + idx % MO_TW;
-            if (gx < w && gy < h) carry_out[(size_t)gy * w + gx] = cur[k];
+        for (int k = 0; k < MO_RPT + 4; ++k) in[k] = p[roff[k]];
+    }
+    int buf = 0;
+    for (; f < f_end; ++f, buf ^= 1) {
+        float *vb = v_s[buf];
+#pragma unroll
+        for (int k = 0; k < MO_RPT + 4; ++k) in[k] = in[k] + -128.0f;                 // offset_image, combo.c:236
+#pragma unroll
+        for (int i = 0; i < MO_RPT; ++i)
+            vb[(wv * MO_RPT + i) * MO_VP + lane] = motion_taps<ORDER>(in + i, vcol_avx && avx_row_ok(vy0 + i, h, 2));
+        __syncthreads();
+        if (f + 1 < f_end) {
+            const float *p = ref + (size_t)(f + 1) * frame_stride + xc;
+#pragma unroll
+            for (int k = 0; k < MO_RPT + 4; ++k) in[k] = p[roff[k]];
+        }
+        float win[MO_OPT + 4];
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(vb + hr * MO_VP + ox0);
+            const float4 a = src[0], b = src[1], c = (ox0 + 8 < MO_CW) ? src[2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            win[0] = a.x; win[1] = a.y; win[2] = a.z; win[3] = a.w;
+            win[4] = b.x; win[5] = b.y; win[6] = b.z; win[7] = b.w;
+            win[8] = c.x; win[9] = c.y; win[10] = c.z; win[11] = c.w;
+        }
+        const bool scored = f >= f_begin && (f > 0 || has_carry);
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < MO_OPT; ++j) {
+            const int gx = x0 + ox0 + j;
+            cur[j] = motion_taps<ORDER>(win + j, ORDER == ORDER_AVX && gx >= 2 && gx < hend);
+            if (scored && ox0 + j < MO_TW && gx < w && gy < h) acc += (double)fabsf(prev[j] - cur[j]);
+            prev[j] = cur[j];
+        }
+        if (f >= f_begin) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            if (lane == 0) partial[((size_t)f * ntiles + tile) * MO_WAVES + wv] = acc;
+        }
+    }
+    if (carry_out && f_end == nframes) {
+#pragma unroll
+        for (int j = 0; j < MO_OPT; ++j) {
+            const int gx = x0 + ox0 + j;
+            if (ox0 + j < MO_TW && gx < w && gy < h) carry_out[(size_t)gy * w + gx] = prev[j];
         }
     }
 }
@@ -865,7 +862,6 @@ __global__ __launch_bounds__(256) void svm_rbf_kernel(const double *__restrict__
     if (threadIdx.x == 0) out[blockIdx.x] = total - rho;
 }
 
-inline dim3 grid_for(int w, int h, int tw, int th, int nframes) { return dim3((w + tw - 1) / tw, (h + th - 1) / th, nframes); }
 // tiles flattened into grid.x (XCD-aware order inside the kernel), frames in grid.z
 inline dim3 grid_flat(int w, int h, int tw, int th, int nframes) { return dim3(((w + tw - 1) / tw) * ((h + th - 1) / th), 1, nframes); }
 
@@ -880,7 +876,7 @@ int vk_adm_tiles(int w, int h)
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     return ((bw + ADM_TW - 1) / ADM_TW) * ((bh + ADM_TH - 1) / ADM_TH);
 }
-int vk_motion_tiles(int w, int h) { return ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH); }
+int vk_motion_tiles(int w, int h) { return ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH) * MO_WAVES; }   // partial doubles per frame
 
 int vk_vif_border_tiles(int scale, int w, int h)
 {
@@ -939,11 +935,19 @@ hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, si
 hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
                             const float *carry_in, float *carry_out, double *partial, hipStream_t s)
 {
-    const dim3 g = grid_for(w, h, MO_TW, MO_TH, 1);     // one workgroup per tile walks through the frames
+    // workgroup = (tile, chunk of frames): enough chunks for ~2 resident rounds of workgroups, each chunk
+    // pays one extra blur (of the frame before it), so chunks stay as long as that allows
+    static const int forced = getenv("VMAF_HIP_MOTION_CHUNK") ? atoi(getenv("VMAF_HIP_MOTION_CHUNK")) : 0;
+    const int tiles = ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH);
+    int nchunks = (4096 + tiles - 1) / tiles;
+    if (nchunks > nframes) nchunks = nframes;
+    int chunk = forced > 0 ? forced : (nframes + nchunks - 1) / nchunks;
+    if (chunk < 1) chunk = 1;
+    const dim3 g(tiles, (nframes + chunk - 1) / chunk, 1);
     if (order == ORDER_SCALAR)
-        motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
+        motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
     else
-        motion_kernel<ORDER_AVX><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, has_carry, carry_in, carry_out, partial);
+        motion_kernel<ORDER_AVX><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
     return hipGetLastError();
 }
 
