@@ -53,18 +53,20 @@ template <int FW, bool MOTION> __device__ __forceinline__ constexpr float ftap(i
 
 constexpr int ORDER_SCALAR = 0, ORDER_AVX = 1;
 
-// One output sample from p[0], p[st], .., p[(FW-1)*st], taps accumulated left to right from 0.
+// One output sample from p[0], p[st], .., p[(FW-1)*st], taps accumulated left to right.  The reference starts
+// from 0.0f; starting from the first product gives the same bits (0.0f + x == x) except for the sign of a
+// zero sum, which nothing downstream can see (every consumer squares, compares or adds it).
 template <int FW, bool MOTION> __device__ __forceinline__ float taps_seq_at(const float *p, int st)
 {
-    float acc = 0.0f;
+    float acc = ftap<FW, MOTION>(0) * p[0];
 #pragma unroll
-    for (int k = 0; k < FW; ++k) acc = acc + ftap<FW, MOTION>(k) * p[k * st];
+    for (int k = 1; k < FW; ++k) acc = acc + ftap<FW, MOTION>(k) * p[k * st];
     return acc;
 }
 
 // Same sample in the interior order of the reference's AVX kernels (convolution_avx.c:225-270, :347-392,
 // :408-437, generic :116-205): passes of up to 9 taps; inside a pass tap k goes to partial sum k%4, the pass
-// value is (s0+s2)+(s1+s3); pass values are added in order, the first one to +0.
+// value is (s0+s2)+(s1+s3); pass values are added in order (the first one to +0: see above).
 template <int FW, bool MOTION> __device__ __forceinline__ float taps_avx_at(const float *p, int st)
 {
     float total = 0.0f;
@@ -80,9 +82,21 @@ template <int FW, bool MOTION> __device__ __forceinline__ float taps_avx_at(cons
             }
         }
         const float pass = (sm[0] + sm[2]) + (sm[1] + sm[3]);
-        total = total + pass;
+        total = (x == 0) ? pass : total + pass;
     }
     return total;
+}
+
+// A sample whose order is decided per lane (ORDER_AVX: vector order in the interior, scalar order where the
+// reference falls back to its scalar loops).  The branches are wave-uniform: a wave evaluates an order only
+// if one of its lanes needs it, so interior waves pay for one.
+template <int FW, bool MOTION, int ORDER> __device__ __forceinline__ float taps_sel(const float *p, int st, bool avx)
+{
+    if (ORDER == ORDER_SCALAR) return taps_seq_at<FW, MOTION>(p, st);
+    float ra = 0.0f, rs = 0.0f;
+    if (__any(avx)) ra = taps_avx_at<FW, MOTION>(p, st);
+    if (__any(!avx)) rs = taps_seq_at<FW, MOTION>(p, st);
+    return avx ? ra : rs;
 }
 
 // Where the reference's AVX path uses its vector kernels (convolution_avx.c:799-836):
@@ -268,6 +282,8 @@ template <int FW> struct VifGeom {
     static constexpr int RD = DFW / 2;
     static constexpr int DVW = VIF_TW + 2 * RD;               // columns the decimation's vertical pass produces
     static constexpr int D_FLOATS = DFW ? 2 * (VIF_TH / 2) * DVW : 0;
+    static constexpr int DSH = 3;                             // decimated outputs per thread, horizontal pass
+    static_assert(2 * (VIF_TH / 2) * (VIF_TW / 2 / DSH) == VIF_THREADS && (VIF_TW / 2) % DSH == 0, "one decimation strip per thread");
     static constexpr int IN_FLOATS = 2 * IH * IW;
     static constexpr int V_FLOATS = 5 * VIF_TH * VS;
     static constexpr int SMEM_FLOATS = (IN_FLOATS > V_FLOATS ? IN_FLOATS : V_FLOATS);
@@ -326,6 +342,18 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
             rv[i] = in_r[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
             dv[i] = in_d[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
         }
+        if (DFW > 0 && vc >= R - RD && vc < R - RD + DVW) {
+            // decimation, vertical pass at the even rows (y0 is even) out of the same register windows:
+            // output row y0 + vs*SV + 2i is window element R + 2i, columns x0-RD .. x0+TW+RD-1
+            const bool col_avx = ORDER == ORDER_AVX && avx_vcol_ok(mirror_idx(x0 - R + vc, w), w);
+#pragma unroll
+            for (int i = 0; i < VIF_SV / 2; ++i) {
+                const bool avx = col_avx && avx_row_ok(y0 + vs * VIF_SV + 2 * i, h, RD);
+                const int o = (vs * (VIF_SV / 2) + i) * DVW + vc - (R - RD);
+                dv_s[o] = taps_sel<DFW ? DFW : 3, false, ORDER>(rv + R - RD + 2 * i, 1, avx);
+                dv_s[(VIF_TH / 2) * DVW + o] = taps_sel<DFW ? DFW : 3, false, ORDER>(dv + R - RD + 2 * i, 1, avx);
+            }
+        }
         taps_window<FW, VIF_SV, ORDER>(rv, vo[0]);
         taps_window<FW, VIF_SV, ORDER>(dv, vo[1]);
 #pragma unroll
@@ -338,31 +366,26 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * dv[i];
         taps_window<FW, VIF_SV, ORDER>(t, vo[4]);
     }
-    if (DFW > 0) {
-        // decimation, vertical pass at the even rows (y0 is even): source row y0 + 2*oy, columns x0-RD .. x0+TW+RD-1
-        for (int idx = tid; idx < 2 * (VIF_TH / 2) * DVW; idx += VIF_THREADS) {
-            const int pl = idx / ((VIF_TH / 2) * DVW), rem = idx - pl * ((VIF_TH / 2) * DVW);
-            const int oy = rem / DVW, c = rem - oy * DVW;
-            const float *src = (pl ? in_d : in_r) + (R - RD + 2 * oy) * IW + c + (G::HP - RD);
-            const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + 2 * oy, h, RD) && avx_vcol_ok(mirror_idx(x0 - RD + c, w), w);
-            dv_s[idx] = avx ? taps_avx_at<DFW ? DFW : 3, false>(src, IW) : taps_seq_at<DFW ? DFW : 3, false>(src, IW);
-        }
-    }
     __syncthreads();                                          // input tile fully consumed: alias it
     float *vout = smem;
     if (DFW > 0) {
-        // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes
+        // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes;
+        // thread = (plane, output row, strip of DSH outputs), taps from a register window
+        constexpr int DSH = G::DSH, DNW = 2 * (DSH - 1) + (DFW ? DFW : 1);
+        const int pl = tid / ((VIF_TH / 2) * (VIF_TW / 2 / DSH)), rem = tid - pl * ((VIF_TH / 2) * (VIF_TW / 2 / DSH));
+        const int oy = rem / (VIF_TW / 2 / DSH), ox0 = (rem - oy * (VIF_TW / 2 / DSH)) * DSH;
         const int ow = w / 2, oh = h / 2, dend = avx_hcol_end(w, RD);
-        for (int idx = tid; idx < 2 * (VIF_TH / 2) * (VIF_TW / 2); idx += VIF_THREADS) {
-            const int pl = idx / ((VIF_TH / 2) * (VIF_TW / 2)), rem = idx - pl * ((VIF_TH / 2) * (VIF_TW / 2));
-            const int oy = rem / (VIF_TW / 2), ox = rem - oy * (VIF_TW / 2);
-            const float *src = dv_s + (pl * (VIF_TH / 2) + oy) * DVW + 2 * ox;
-            const int sx = x0 + 2 * ox;
-            const bool avx = ORDER == ORDER_AVX && sx >= RD && sx < dend;
-            const float val = avx ? taps_avx_at<DFW ? DFW : 3, false>(src, 1) : taps_seq_at<DFW ? DFW : 3, false>(src, 1);
-            const int gx = x0 / 2 + ox, gy = y0 / 2 + oy;
-            if (gx < ow && gy < oh)
-                (pl ? odis : oref)[(size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + gx] = val;
+        const float *src = dv_s + (pl * (VIF_TH / 2) + oy) * DVW + 2 * ox0;
+        float dw[DNW];
+#pragma unroll
+        for (int k = 0; k < DNW; ++k) dw[k] = src[k];
+        const int gy = y0 / 2 + oy;
+        float *dst = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + x0 / 2 + ox0;
+#pragma unroll
+        for (int o = 0; o < DSH; ++o) {
+            const int sx = x0 + 2 * (ox0 + o);
+            const float val = taps_sel<DFW ? DFW : 3, false, ORDER>(dw + 2 * o, 1, ORDER == ORDER_AVX && sx >= RD && sx < dend);
+            if (x0 / 2 + ox0 + o < ow && gy < oh) dst[o] = val;
         }
     }
     if (vactive) {
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(BD_THREADS) void vif_border_kernel(const float *__r
         const int oy = rem / VW, c = rem - oy * VW;
         const float *src = &pl[q][oy * IW + c + (HP - R)];
         const bool avx = avx_row_ok(y0 + oy, h, R) && avx_vcol_ok(mirror_idx(x0 - R + c, w), w);
-        vout[q][rem] = avx ? taps_avx_at<FW, false>(src, IW) : taps_seq_at<FW, false>(src, IW);
+        vout[q][rem] = taps_sel<FW, false, ORDER_AVX>(src, IW, avx);
     }
     __syncthreads();
     double acc[2] = { 0.0, 0.0 };
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(BD_THREADS) void vif_border_kernel(const float *__r
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const float *src = &vout[q][oy * VW + ox];
-                f[q] = avx ? taps_avx_at<FW, false>(src, 1) : taps_seq_at<FW, false>(src, 1);
+                f[q] = taps_sel<FW, false, ORDER_AVX>(src, 1, avx);
             }
             float n, d;
             vif_pixel(f[0], f[1], f[2], f[3], f[4], n, d);
@@ -725,16 +748,6 @@ constexpr int MO_VP = MO_CW + 4;                             // LDS row pitch: s
 constexpr int MO_WAVES = MO_THREADS / 64;
 static_assert(MO_CW == 64 && MO_TH * (MO_CW / MO_OPT) == MO_THREADS, "thread maps");
 
-template <int ORDER> __device__ __forceinline__ float motion_taps(const float *v, bool avx)
-{
-    if (ORDER == ORDER_SCALAR) return taps_seq_at<5, true>(v, 1);
-    // wave-uniform branches: a wave evaluates an order only if one of its lanes needs it
-    float ra = 0.0f, rs = 0.0f;
-    if (__any(avx)) ra = taps_avx_at<5, true>(v, 1);
-    if (__any(!avx)) rs = taps_seq_at<5, true>(v, 1);
-    return avx ? ra : rs;
-}
-
 template <int ORDER>
 __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restrict__ ref, size_t frame_stride, int row_stride,
                                                             int w, int h, int nframes, int chunk, int has_carry,
@@ -786,7 +799,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
         for (int k = 0; k < MO_RPT + 4; ++k) in[k] = in[k] + -128.0f;                 // offset_image, combo.c:236
 #pragma unroll
         for (int i = 0; i < MO_RPT; ++i)
-            vb[(wv * MO_RPT + i) * MO_VP + lane] = motion_taps<ORDER>(in + i, vcol_avx && avx_row_ok(vy0 + i, h, 2));
+            vb[(wv * MO_RPT + i) * MO_VP + lane] = taps_sel<5, true, ORDER>(in + i, 1, vcol_avx && avx_row_ok(vy0 + i, h, 2));
         __syncthreads();
         if (f + 1 < f_end) {
             const float *p = ref + (size_t)(f + 1) * frame_stride + xc;
@@ -806,7 +819,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
 #pragma unroll
         for (int j = 0; j < MO_OPT; ++j) {
             const int gx = x0 + ox0 + j;
-            cur[j] = motion_taps<ORDER>(win + j, ORDER == ORDER_AVX && gx >= 2 && gx < hend);
+            cur[j] = taps_sel<5, true, ORDER>(win + j, 1, ORDER == ORDER_AVX && gx >= 2 && gx < hend);
             if (scored && ox0 + j < MO_TW && gx < w && gy < h) acc += (double)fabsf(prev[j] - cur[j]);
             prev[j] = cur[j];
         }
