@@ -4,6 +4,7 @@
 # 2. rocprofv3 --kernel-trace --stats of the same command       -> gpurun_out/<tag>/stats/
 # 3. FETCH_SIZE and WRITE_SIZE in separate --pmc passes         -> gpurun_out/<tag>/pmc_fetch, pmc_write
 #    (short run: the counters are per launch, 2 steps are enough)
+# 4. one-stream run: exclusive kernel durations + VALU/LDS counters  -> gpurun_out/<tag>/stats_serial, pmc_valu
 # tools/summarize_profiles.py then turns these into the tracked files under profiles/.
 set -e
 tag=${1:-r01}
@@ -16,5 +17,10 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o vm -- python3 "$root/bench.py" --no-cpu-baseline > "$out/stats.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$out/pmc_fetch.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$out/pmc_write.log" 2>&1
+# 4. VALU / LDS issue counters and exclusive kernel durations, one stream (VMAF_HIP_SERIAL=1)
+export VMAF_HIP_SERIAL=1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_valu" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$out/pmc_valu.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_serial" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --steps 10 > "$out/stats_serial.log" 2>&1
+unset VMAF_HIP_SERIAL
 cd "$root"
 tail -1 "$out/bench.json"

@@ -69,6 +69,27 @@ def main():
                        "width": 1920, "height": 1080, "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],
                        "note": "FETCH_SIZE (KB) x2 [gfx950 correction] + WRITE_SIZE (KB), separate --pmc passes"},
                       open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    ser = glob.glob(os.path.join(src, "stats_serial", "**", "*kernel_stats.csv"), recursive=True)
+    dur = {}
+    if ser:
+        shutil.copy(ser[0], os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))
+        for r in csv.DictReader(open(ser[0])):
+            dur[short(r["Name"])] = float(r["AverageNs"])
+    names = ["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES",
+             "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+    cnt = {n: counters(os.path.join(src, "pmc_valu"), n) for n in names}
+    kernels = sorted(set(k for n in names for k in cnt[n]), key=lambda k: -dur.get(k, 0))
+    if kernels:
+        with open(os.path.join(dst, f"{tag}_valu_counters.csv"), "w", newline="") as fh:
+            wr = csv.writer(fh)
+            # valu_issue_frac: wave-level VALU instructions x 4 cycles (wave64 on a SIMD16) over the cycles the 1024 SIMDs
+            # of the chip offer during the kernel's exclusive duration at the 2.4 GHz peak engine clock
+            wr.writerow(["kernel", "exclusive_us"] + names + ["valu_issue_frac_at_2.4GHz"])
+            for k in kernels:
+                row = [cnt[n].get(k, (0.0, 0))[0] for n in names]
+                d = dur.get(k)
+                frac = round(row[0] * 4 / (1024 * d * 1e-9 * 2.4e9), 3) if d else ""
+                wr.writerow([k, round(d / 1e3, 1) if d else ""] + [int(x) for x in row] + [frac])
     print("wrote", sorted(os.listdir(dst)))
 
 

@@ -76,7 +76,7 @@ struct vmaf_hip_engine {
     float *stage_ref = nullptr, *stage_dis = nullptr;
     double *partials = nullptr, *sums_dev = nullptr, *sums_host = nullptr;
     size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
-    int tiles_vif[4], tiles_vif_border[4], tiles_adm[4], tiles_mot;
+    int tiles_vif[4], tiles_adm[4], tiles_mot;
     float rfac[8];
     int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
 
@@ -154,9 +154,6 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
         HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc],
                                    nr, nd, nfs, nrs, e->s_main));
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1, e->s_main));
-        if (e->order == 1)   // the border frame of the AVX order: its blocks' partials follow the tile kernel's
-            HIP_TRY(vk_launch_vif_border(sc, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes,
-                                         e->partials + e->part_off_vif[sc] + (size_t)nframes * e->tiles_vif[sc] * 2, e->s_main));
         cr = nr; cd = nd; cfs = nfs; crs = nrs;
     }
 
@@ -187,8 +184,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     int q = 0;
     for (int sc = 0; sc < 4; ++sc)
         for (int c = 0; c < 2; ++c)
-            tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c, e->part_off_vif[sc] + (size_t)nframes * e->tiles_vif[sc] * 2,
-                           e->order == 1 ? e->tiles_vif_border[sc] : 0 };
+            tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c, 0, 0 };
     for (int sc = 0; sc < 4; ++sc)
         for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c, 0, 0 };
     tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0, 0, 0 };
@@ -280,9 +276,8 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     size_t off = 0;
     for (int s = 0; s < 4; ++s) {
         e->tiles_vif[s] = vk_vif_tiles(e->vw[s], e->vh[s]);
-        e->tiles_vif_border[s] = vk_vif_border_tiles(s, e->vw[s], e->vh[s]);
         e->part_off_vif[s] = off;
-        off += B * (e->tiles_vif[s] + e->tiles_vif_border[s]) * 2;
+        off += B * e->tiles_vif[s] * 2;
     }
     for (int s = 0; s < 4; ++s) { e->tiles_adm[s] = vk_adm_tiles(e->aw[s], e->ah[s]); e->part_off_adm[s] = off; off += B * e->tiles_adm[s] * 6; }
     e->tiles_mot = vk_motion_tiles(width, height); e->part_off_mot = off; off += B * e->tiles_mot;

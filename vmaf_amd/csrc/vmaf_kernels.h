@@ -6,7 +6,7 @@
 #include <stddef.h>
 
 // Per-frame raw sums produced on the device, finished into the 20 atoms on the host:
-//   [0..7]   VIF  num,den of scale 0..3 (tile kernel blocks followed by border kernel blocks)
+//   [0..7]   VIF  num,den of scale 0..3
 //   [8..31]  ADM  scale s: num_h,num_v,num_d,den_h,den_v,den_d  (cube sums over the centre window)
 //   [32]     motion: sum |blur_prev - blur_cur|
 #define VK_NSUMS 33
@@ -16,7 +16,7 @@ typedef struct {
     int ntiles;      // blocks per frame in the producing kernel
     int k;           // doubles per block
     int comp;        // which of the k this sum takes
-    size_t offset2;  // optional second section with the same k (VIF border blocks); ntiles2 = 0 when unused
+    size_t offset2;  // optional second section with the same k; ntiles2 = 0 when unused
     int ntiles2;
 } vk_reduce_desc;
 
@@ -30,13 +30,11 @@ int vk_vif_tiles(int w, int h);
 int vk_adm_tiles(int w, int h);     // w,h = INPUT size of the scale
 int vk_motion_tiles(int w, int h);
 
-// order: 0 = the reference's scalar tap order (disable_avx), 1 = its AVX order (default on x86)
+// order: 0 = the reference's scalar tap order (disable_avx), 1 = its AVX order (default on x86; two launches:
+// interior tiles, then the border-frame tiles with per-sample order - same partial slots)
 hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s);
-int vk_vif_border_tiles(int scale, int w, int h);
-hipError_t vk_launch_vif_border(int scale, const float *ref, const float *dis, size_t frame_stride, int row_stride,
-                                int w, int h, int nframes, double *partial, hipStream_t s);
 hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,

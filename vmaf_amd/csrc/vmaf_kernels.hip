@@ -105,11 +105,6 @@ template <int FW, bool MOTION, int ORDER> __device__ __forceinline__ float taps_
 __host__ __device__ __forceinline__ bool avx_row_ok(int gy, int h, int r) { return gy >= r && gy < h - r; }
 __host__ __device__ __forceinline__ bool avx_vcol_ok(int gx, int w) { return gx < (w & ~7); }
 __host__ __device__ __forceinline__ int avx_hcol_end(int w, int r) { return r + (w & ~7) - ((r + 1 + 7) & ~7); }
-// A pixel whose value involves no scalar-order sample at all (every other pixel is "border frame")
-__host__ __device__ __forceinline__ bool avx_pure_pixel(int gx, int gy, int w, int h, int r)
-{
-    return avx_row_ok(gy, h, r) && gx >= r && gx < avx_hcol_end(w, r);
-}
 
 // Mirror rule of every stencil on the path (vif_tools.c:301, adm_tools.c:241-248); the final
 // clamp only matters for tiles hanging over the image, whose results are masked out.
@@ -301,11 +296,61 @@ __device__ __forceinline__ void taps_window(const float *v, float *out)
         out[o] = (ORDER == ORDER_SCALAR) ? taps_seq_at<FW, false>(v + o, 1) : taps_avx_at<FW, false>(v + o, 1);
 }
 
+// Same with the order chosen per output (bit o of avx_mask): the tiles on the border frame of ORDER_AVX
+// (most waves of those tiles still agree on one order for the whole window and keep its instruction-level parallelism)
+template <int FW, int NOUT> __device__ __forceinline__ void taps_window_sel(const float *v, float *out, unsigned avx_mask)
+{
+    constexpr unsigned ALL = (1u << NOUT) - 1u;
+    if (__all(avx_mask == ALL)) {
+        taps_window<FW, NOUT, ORDER_AVX>(v, out);
+    } else if (__all(avx_mask == 0u)) {
+        taps_window<FW, NOUT, ORDER_SCALAR>(v, out);
+    } else {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) out[o] = taps_sel<FW, false, ORDER_AVX>(v + o, 1, (avx_mask >> o) & 1u);
+    }
+}
+
+// Tiles of a VIF scale that contain a pixel which is not avx_pure_pixel (the "border frame" of ORDER_AVX):
+// tile rows {0} u [ty_b, nty) completely, and in the other rows tile columns {0} u [tx_r, ntx).
+struct BorderGeom { int ntx, nty, ty_b, tx_r, nrs, ncs, ntiles; };
+__host__ __device__ inline BorderGeom border_geom(int w, int h, int r, int tw, int th)
+{
+    BorderGeom g;
+    g.ntx = (w + tw - 1) / tw;
+    g.nty = (h + th - 1) / th;
+    const int hb = h - r > 0 ? h - r : 0, he = avx_hcol_end(w, r) > 0 ? avx_hcol_end(w, r) : 0;
+    g.ty_b = hb / th > 1 ? hb / th : 1;
+    g.tx_r = he / tw > 1 ? he / tw : 1;
+    if (g.ty_b > g.nty) g.ty_b = g.nty;
+    if (g.tx_r > g.ntx) g.tx_r = g.ntx;
+    g.nrs = 1 + g.nty - g.ty_b;
+    g.ncs = 1 + g.ntx - g.tx_r;
+    g.ntiles = g.nrs * g.ntx + (g.ty_b - 1) * g.ncs;
+    return g;
+}
+__device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &tx, int &ty)
+{
+    if (b < g.nrs * g.ntx) {
+        const int rr = b / g.ntx;
+        tx = b - rr * g.ntx;
+        ty = rr == 0 ? 0 : g.ty_b + rr - 1;
+    } else {
+        const int bb = b - g.nrs * g.ntx, c = bb % g.ncs;
+        ty = 1 + bb / g.ncs;
+        tx = c == 0 ? 0 : g.tx_r + c - 1;
+    }
+}
+
 // Fused VIF scale kernel. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products,
 // three filtered moments, vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.
 // From the same staged tile it also produces the next scale's input (vif.c:157-186): blur with the NEXT
 // scale's filter, evaluated at even rows/columns only, so ref/dis are read from HBM once per scale.
-template <int FW, bool OFFSET, int ORDER>
+// ORDER_AVX comes as two launches over disjoint tile sets: BORDER = false covers the tiles whose every sample is
+// in the vector order (it leaves the others at once), BORDER = true the border-frame tiles, where every sample
+// picks its order exactly as convolution_f32_avx_s_1d does (convolution_avx.c:806-836); both write
+// partial[frame][tile] and the decimated planes of their own tiles.
+template <int FW, bool OFFSET, int ORDER, bool BORDER>
 __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                                size_t frame_stride, int row_stride, int w, int h,
                                                                double *__restrict__ partial,
@@ -322,7 +367,21 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
 
     const int tid = threadIdx.x;
     const int ntx = (w + VIF_TW - 1) / VIF_TW;
-    const int tile_id = xcd_tile_index();
+    int tile_id;
+    if (ORDER == ORDER_AVX) {
+        const BorderGeom bg = border_geom(w, h, R, VIF_TW, VIF_TH);
+        if (BORDER) {
+            int tx, ty;
+            border_tile_at(bg, blockIdx.x, tx, ty);
+            tile_id = ty * ntx + tx;
+        } else {                                              // the interior tiles form the rectangle [1, tx_r) x [1, ty_b)
+            const int i = xcd_tile_index(), iw = bg.tx_r - 1;
+            tile_id = (1 + i / iw) * ntx + 1 + i % iw;
+        }
+    } else {
+        tile_id = xcd_tile_index();
+    }
+    const int ntiles = ntx * ((h + VIF_TH - 1) / VIF_TH);
     const int x0 = (tile_id % ntx) * VIF_TW, y0 = (tile_id / ntx) * VIF_TH;
     const float *fr = ref + (size_t)blockIdx.z * frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * frame_stride;
@@ -354,17 +413,26 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
                 dv_s[(VIF_TH / 2) * DVW + o] = taps_sel<DFW ? DFW : 3, false, ORDER>(dv + R - RD + 2 * i, 1, avx);
             }
         }
-        taps_window<FW, VIF_SV, ORDER>(rv, vo[0]);
-        taps_window<FW, VIF_SV, ORDER>(dv, vo[1]);
+        unsigned vmask = 0;                                   // BORDER: vector order iff row and column both allow it
+        if (BORDER && avx_vcol_ok(mirror_idx(x0 - R + vc, w), w)) {
+#pragma unroll
+            for (int o = 0; o < VIF_SV; ++o) vmask |= avx_row_ok(y0 + vs * VIF_SV + o, h, R) ? 1u << o : 0u;
+        }
+#define VIF_VPASS(src, q)                                                  \
+        if (BORDER) taps_window_sel<FW, VIF_SV>(src, vo[q], vmask);        \
+        else taps_window<FW, VIF_SV, ORDER>(src, vo[q])
+        VIF_VPASS(rv, 0);
+        VIF_VPASS(dv, 1);
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * rv[i];
-        taps_window<FW, VIF_SV, ORDER>(t, vo[2]);
+        VIF_VPASS(t, 2);
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = dv[i] * dv[i];
-        taps_window<FW, VIF_SV, ORDER>(t, vo[3]);
+        VIF_VPASS(t, 3);
 #pragma unroll
         for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * dv[i];
-        taps_window<FW, VIF_SV, ORDER>(t, vo[4]);
+        VIF_VPASS(t, 4);
+#undef VIF_VPASS
     }
     __syncthreads();                                          // input tile fully consumed: alias it
     float *vout = smem;
@@ -401,6 +469,15 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
     {
         const int row = tid % VIF_TH, strip = tid / VIF_TH;
         float ho[5][VIF_SH];
+        unsigned hmask = 0;
+        if (BORDER) {
+            const int hend = avx_hcol_end(w, R);
+#pragma unroll
+            for (int o = 0; o < VIF_SH; ++o) {
+                const int gx = x0 + strip * VIF_SH + o;
+                hmask |= (gx >= R && gx < hend) ? 1u << o : 0u;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             float v[G::NV];
@@ -410,7 +487,8 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
                 const float2 f2 = p[m];
                 v[2 * m] = f2.x; v[2 * m + 1] = f2.y;
             }
-            taps_window<FW, VIF_SH, ORDER>(v, ho[q]);
+            if (BORDER) taps_window_sel<FW, VIF_SH>(v, ho[q], hmask);
+            else taps_window<FW, VIF_SH, ORDER>(v, ho[q]);
         }
         const int gy = y0 + row;
 #pragma unroll
@@ -418,103 +496,13 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
             const int gx = x0 + strip * VIF_SH + o;
             float n, d;
             vif_pixel(ho[0][o], ho[1][o], ho[2][o], ho[3][o], ho[4][o], n, d);
-            // ORDER_AVX: the border frame belongs to vif_border_kernel
-            const bool mine = gx < w && gy < h && (ORDER == ORDER_SCALAR || avx_pure_pixel(gx, gy, w, h, R));
+            const bool mine = gx < w && gy < h;
             if (mine) { acc[0] += (double)n; acc[1] += (double)d; }
         }
     }
     __syncthreads();                                          // vout fully consumed: alias for the reduction
-    const size_t tile = (size_t)blockIdx.z * gridDim.x + tile_id;
+    const size_t tile = (size_t)blockIdx.z * ntiles + tile_id;
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
-}
-
-// ---------------------------------------------------------------- VIF border frame (ORDER_AVX)
-constexpr int BD_T = 16, BD_THREADS = 256;
-
-struct BorderGeom { int nx, ny, ty_b, tx_r, nrs, ncs, ntiles; };
-// 16x16 tiles that intersect the frame of pixels which is not avx_pure_pixel: tile rows {0} u [ty_b, ny)
-// completely, and in the other rows tile columns {0} u [tx_r, nx).
-__host__ __device__ inline BorderGeom border_geom(int w, int h, int r)
-{
-    BorderGeom g;
-    g.nx = (w + BD_T - 1) / BD_T;
-    g.ny = (h + BD_T - 1) / BD_T;
-    const int hb = h - r > 0 ? h - r : 0, he = avx_hcol_end(w, r) > 0 ? avx_hcol_end(w, r) : 0;
-    g.ty_b = hb / BD_T > 1 ? hb / BD_T : 1;
-    g.tx_r = he / BD_T > 1 ? he / BD_T : 1;
-    if (g.ty_b > g.ny) g.ty_b = g.ny;
-    if (g.tx_r > g.nx) g.tx_r = g.nx;
-    g.nrs = 1 + g.ny - g.ty_b;
-    g.ncs = 1 + g.nx - g.tx_r;
-    g.ntiles = g.nrs * g.nx + (g.ty_b - 1) * g.ncs;
-    return g;
-}
-
-// The pixels of one VIF scale whose value involves scalar-order samples in the reference's AVX path: same
-// arithmetic as vif_stat_kernel, but every sample picks its order exactly as convolution_f32_avx_s_1d does
-// (convolution_avx.c:806-836).  About 2 % of the pixels, so a plain LDS-direct formulation.
-template <int FW, bool OFFSET>
-__global__ __launch_bounds__(BD_THREADS) void vif_border_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
-                                                                size_t frame_stride, int row_stride, int w, int h,
-                                                                double *__restrict__ partial)
-{
-    constexpr int R = FW / 2, HP = (R + 3) / 4 * 4;
-    constexpr int IW = BD_T + 2 * HP, IH = BD_T + 2 * R, VW = BD_T + 2 * R;
-    __shared__ __attribute__((aligned(16))) float pl[5][IH * IW];       // r, d, then r*r, d*d, r*d
-    __shared__ float vout[5][BD_T * VW];
-    __shared__ double red[(BD_THREADS / 64) * 2];
-    const BorderGeom g = border_geom(w, h, R);
-    const int b = blockIdx.x, tid = threadIdx.x;
-    int tx, ty;
-    if (b < g.nrs * g.nx) {
-        const int rr = b / g.nx;
-        tx = b - rr * g.nx;
-        ty = rr == 0 ? 0 : g.ty_b + rr - 1;
-    } else {
-        const int bb = b - g.nrs * g.nx, c = bb % g.ncs;
-        ty = 1 + bb / g.ncs;
-        tx = c == 0 ? 0 : g.tx_r + c - 1;
-    }
-    const int x0 = tx * BD_T, y0 = ty * BD_T;
-    const float *fr = ref + (size_t)blockIdx.z * frame_stride;
-    const float *fd = dis + (size_t)blockIdx.z * frame_stride;
-    stage_tile<IH, IW, BD_THREADS, OFFSET, true>(fr, fd, row_stride, w, h, x0 - HP, y0 - R, pl[0], pl[1]);
-    __syncthreads();
-    for (int idx = tid; idx < IH * IW; idx += BD_THREADS) {
-        const float a = pl[0][idx], c = pl[1][idx];
-        pl[2][idx] = a * a;
-        pl[3][idx] = c * c;
-        pl[4][idx] = a * c;
-    }
-    __syncthreads();
-    const int hend = avx_hcol_end(w, R);
-    for (int idx = tid; idx < 5 * BD_T * VW; idx += BD_THREADS) {
-        const int q = idx / (BD_T * VW), rem = idx - q * (BD_T * VW);
-        const int oy = rem / VW, c = rem - oy * VW;
-        const float *src = &pl[q][oy * IW + c + (HP - R)];
-        const bool avx = avx_row_ok(y0 + oy, h, R) && avx_vcol_ok(mirror_idx(x0 - R + c, w), w);
-        vout[q][rem] = taps_sel<FW, false, ORDER_AVX>(src, IW, avx);
-    }
-    __syncthreads();
-    double acc[2] = { 0.0, 0.0 };
-    {
-        const int oy = tid / BD_T, ox = tid - oy * BD_T;
-        const int gx = x0 + ox, gy = y0 + oy;
-        if (gx < w && gy < h && !avx_pure_pixel(gx, gy, w, h, R)) {
-            const bool avx = gx >= R && gx < hend;
-            float f[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const float *src = &vout[q][oy * VW + ox];
-                f[q] = taps_sel<FW, false, ORDER_AVX>(src, 1, avx);
-            }
-            float n, d;
-            vif_pixel(f[0], f[1], f[2], f[3], f[4], n, d);
-            acc[0] = (double)n;
-            acc[1] = (double)d;
-        }
-    }
-    block_reduce_store<2, BD_THREADS / 64>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2);
 }
 
 // ---------------------------------------------------------------- ADM
@@ -891,20 +879,22 @@ int vk_adm_tiles(int w, int h)
 }
 int vk_motion_tiles(int w, int h) { return ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH) * MO_WAVES; }   // partial doubles per frame
 
-int vk_vif_border_tiles(int scale, int w, int h)
-{
-    static const int fw[4] = { 17, 9, 5, 3 };
-    return border_geom(w, h, fw[scale] / 2).ntiles;
-}
-
 hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s)
 {
+    static const int fw[4] = { 17, 9, 5, 3 };
     const dim3 g = grid_flat(w, h, VIF_TW, VIF_TH, nframes);
-#define VIF_STAT(FW, OFF)                                                                                                   \
-    if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride); \
-    else vif_stat_kernel<FW, OFF, ORDER_AVX><<<g, VIF_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride)
+    const BorderGeom bg = border_geom(w, h, fw[scale] / 2, VIF_TW, VIF_TH);
+    const dim3 gb(bg.ntiles, 1, nframes), gi((bg.tx_r - 1) * (bg.ty_b - 1), 1, nframes);   // border frame, interior rectangle
+#define VIF_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+#define VIF_STAT(FW, OFF)                                                                              \
+    if (order == ORDER_SCALAR) {                                                                       \
+        vif_stat_kernel<FW, OFF, ORDER_SCALAR, false><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);             \
+    } else {                                                                                           \
+        if (gi.x > 0) vif_stat_kernel<FW, OFF, ORDER_AVX, false><<<gi, VIF_THREADS, 0, s>>>(VIF_ARGS); \
+        if (gb.x > 0) vif_stat_kernel<FW, OFF, ORDER_AVX, true><<<gb, VIF_THREADS, 0, s>>>(VIF_ARGS);  \
+    }
     switch (scale) {
     case 0: VIF_STAT(17, true); break;
     case 1: VIF_STAT(9, false); break;
@@ -912,20 +902,7 @@ hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const floa
     default: VIF_STAT(3, false); break;
     }
 #undef VIF_STAT
-    return hipGetLastError();
-}
-
-// ORDER_AVX only: the border frame of one scale; partial receives vk_vif_border_tiles() * 2 doubles per frame
-hipError_t vk_launch_vif_border(int scale, const float *ref, const float *dis, size_t frame_stride, int row_stride,
-                                int w, int h, int nframes, double *partial, hipStream_t s)
-{
-    const dim3 g(vk_vif_border_tiles(scale, w, h), 1, nframes);
-    switch (scale) {
-    case 0: vif_border_kernel<17, true><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    case 1: vif_border_kernel<9, false><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    case 2: vif_border_kernel<5, false><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    default: vif_border_kernel<3, false><<<g, BD_THREADS, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial); break;
-    }
+#undef VIF_ARGS
     return hipGetLastError();
 }
 
