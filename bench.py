@@ -45,17 +45,22 @@ VIF0_BYTES_PER_PX = 10.0        # dominant kernel: reads the fp32 ref and dis pl
                                 # two decimated planes of the next VIF scale (2 x 4 B / 4 px = 2 B/px)
 
 
-def measured_traffic(frames_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json, written
-    by tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this bench;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile matches."""
+VALU_PEAK_WINST = 1024 * 2.4e9 / 2   # wave64 fp32 VALU instructions/s: 256 CUs x 4 SIMDs, one per 2 cycles at 2.4 GHz
+                                     # (MI355X_MICROARCH.md: 157 TFLOP/s fp32 vector = this rate x 64 lanes x 2 flop)
+
+
+def committed_profile(frames_per_launch):
+    """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes (profiles/traffic.json,
+    written by tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU runs of this
+    bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  {} when no profile matches."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if (t["width"], t["height"]) != (W, H):
-            return None
-        return int(t["hbm_bytes_per_launch"] * frames_per_launch / t["frames_per_launch"])
+            return {}
+        k = frames_per_launch / t["frames_per_launch"]
+        return {"traffic": int(t["hbm_bytes_per_launch"] * k), "valu": int(t.get("valu_wave_insts_per_launch", 0) * k)}
     except (OSError, KeyError, ValueError):
-        return None
+        return {}
 
 
 def cpu_baseline(ref, dis, budget_s=20.0, max_frames=64):
@@ -143,11 +148,18 @@ def main():
         roof = None
         if kernel_ms:
             achieved = VIF0_BYTES_PER_PX * W * H * B / (kernel_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "vif_stat_kernel<17> (VIF scale 0, fused)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(B),
-                    "algorithmic_bytes": int(VIF0_BYTES_PER_PX * W * H * B),
+            prof = committed_profile(B)
+            roof = {"bound": "hbm", "kernel": "vif_stat_kernel<17> (VIF scale 0, fused; interior + border-frame launches)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": prof.get("traffic"), "algorithmic_bytes": int(VIF0_BYTES_PER_PX * W * H * B),
                     "launch_ms": round(kernel_ms, 4), "frames_per_launch": B,
                     "path_achieved_gbs": round(PATH_BYTES_PER_PX * W * H * fps / world / 1e9, 1)}
+            if prof.get("valu"):
+                # what actually binds this kernel: fp32 VALU issue, unfused mul + add by the parity rule
+                rate = prof["valu"] / (kernel_ms * 1e-3)
+                roof["valu_issue"] = {"wave_insts_per_launch": prof["valu"], "achieved": round(rate / 1e12, 3),
+                                      "peak": round(VALU_PEAK_WINST / 1e12, 3), "unit": "T wave-inst/s",
+                                      "frac": round(rate / VALU_PEAK_WINST, 3)}
         line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",
                 "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

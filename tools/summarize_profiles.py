@@ -63,12 +63,6 @@ def main():
             wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
             wr.writeheader()
             wr.writerows(rows)
-        dom = next((r for r in rows if r["kernel"].startswith("vif_stat_kernel<17")), None)
-        if dom:
-            json.dump({"source": f"profiles/{tag}_hbm_traffic.csv", "kernel": dom["kernel"], "frames_per_launch": frames,
-                       "width": 1920, "height": 1080, "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"],
-                       "note": "FETCH_SIZE (KB) x2 [gfx950 correction] + WRITE_SIZE (KB), separate --pmc passes"},
-                      open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     ser = glob.glob(os.path.join(src, "stats_serial", "**", "*kernel_stats.csv"), recursive=True)
     dur = {}
     if ser:
@@ -82,14 +76,27 @@ def main():
     if kernels:
         with open(os.path.join(dst, f"{tag}_valu_counters.csv"), "w", newline="") as fh:
             wr = csv.writer(fh)
-            # valu_issue_frac: wave-level VALU instructions x 4 cycles (wave64 on a SIMD16) over the cycles the 1024 SIMDs
-            # of the chip offer during the kernel's exclusive duration at the 2.4 GHz peak engine clock
+            # valu_issue_frac: wave-level VALU instructions x 2 cycles (a wave64 fp32 op occupies a SIMD for 2 cycles on
+            # gfx950: 157 TFLOP/s = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz) over the cycles the 1024 SIMDs offer
+            # during the kernel's exclusive duration at the 2.4 GHz peak engine clock
             wr.writerow(["kernel", "exclusive_us"] + names + ["valu_issue_frac_at_2.4GHz"])
             for k in kernels:
                 row = [cnt[n].get(k, (0.0, 0))[0] for n in names]
                 d = dur.get(k)
-                frac = round(row[0] * 4 / (1024 * d * 1e-9 * 2.4e9), 3) if d else ""
+                frac = round(row[0] * 2 / (1024 * d * 1e-9 * 2.4e9), 3) if d else ""
                 wr.writerow([k, round(d / 1e3, 1) if d else ""] + [int(x) for x in row] + [frac])
+    # the dominant kernel = VIF scale 0 = the two launches of vif_stat_kernel<17,...> (interior tiles, border-frame tiles)
+    dom = [r for r in rows if r["kernel"].startswith("vif_stat_kernel<17")]
+    if dom:
+        valu = sum(cnt["SQ_INSTS_VALU"].get(r["kernel"], (0.0, 0))[0] for r in dom)
+        json.dump({"source": f"profiles/{tag}_hbm_traffic.csv, profiles/{tag}_valu_counters.csv",
+                   "kernels": [r["kernel"] for r in dom], "frames_per_launch": frames, "width": 1920, "height": 1080,
+                   "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] for r in dom),
+                   "valu_wave_insts_per_launch": int(valu),
+                   "exclusive_us": round(sum(dur.get(r["kernel"], 0.0) for r in dom) / 1e3, 1),
+                   "note": "FETCH_SIZE (KB) x2 [gfx950 correction] + WRITE_SIZE (KB), separate --pmc passes; "
+                           "SQ_INSTS_VALU = wave-level VALU instructions"},
+                  open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(dst)))
 
 
