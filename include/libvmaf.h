@@ -43,6 +43,18 @@ double compute_vmaf(char* fmt, int width, int height, int (*read_frame)(float *r
 int compute_vmaf_noexcept(double *score, char* fmt, int width, int height, int (*read_frame)(float *ref_data, float *main_data, float *temp_data, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len);
 
 /*
+ * compute_vmaf with raw-luma hand-over.  No counterpart in the reference, whose file-backed callback
+ * converts every sample to fp32 on one host thread (feature/src/common/frame.c:26-129 -> file_io.c:86-172) before
+ * the library sees it.  Here the callback copies the luma plane of ref and dis AS THE FILE HOLDS IT - 8-bit samples,
+ * or 16-bit little-endian words for the *10le formats (decided from fmt) - into the library's page-locked buffers
+ * (dense rows, stride_byte = width * bytes per sample) and skips the chroma itself; the GPU widens to fp32
+ * (/ 4.0 for words, no masking) and applies the -128 offset.  Same return values as read_frame (0 / 2 / 1), same
+ * arguments, outputs, logs and exceptions as compute_vmaf; scores are bit-identical to the fp32 path.
+ */
+double compute_vmaf_raw(char* fmt, int width, int height, int (*read_frame_raw)(void *ref_luma, void *main_luma, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method);
+int compute_vmaf_raw_noexcept(double *score, char* fmt, int width, int height, int (*read_frame_raw)(void *ref_luma, void *main_luma, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len);
+
+/*
  * Fusion half only (wrapper/src/vmaf.cpp:351-559): atoms [nframes][20] (layout in vmaf_hip.h) ->
  * per-frame VMAF scores and the derived feature vectors named by the model, in model order
  * (features_out: [nframes][n_features], may be NULL).  The SVR runs on `device`.  Returns 0 on success.

@@ -90,6 +90,27 @@ int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const fl
 int vmaf_hip_engine_sync(vmaf_hip_engine *e);
 
 /*
+ * Raw-luma forms of the four extract calls: the planes hold the samples as the YUV file does -
+ * bytes_per_sample 1 = 8-bit, 2 = 16-bit little-endian words (the *10le formats) - and the GPU does the
+ * conversion the reference does on the host while reading: (float)px, or (float)px / 4.0 for words, no masking
+ * to 10 bits (feature/src/common/file_io.c:86-172, read_image_b2s / read_image_w2s called from
+ * feature/src/common/frame.c:44-78).  A quarter (half) of the fp32 bytes cross PCIe.  Strides in bytes,
+ * multiples of bytes_per_sample.  Results are bit-identical to the fp32 calls on the converted planes.
+ */
+int vmaf_hip_extract_host_raw(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample,
+                              size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                              int continue_sequence, double *atoms_out);
+int vmaf_hip_extract_device_raw(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bytes_per_sample,
+                                size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                                int continue_sequence, double *atoms_out);
+int vmaf_hip_extract_host_raw_async(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample,
+                                    size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                                    int continue_sequence, double *atoms_out);
+int vmaf_hip_extract_device_raw_async(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bytes_per_sample,
+                                      size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
+                                      int continue_sequence, double *atoms_out);
+
+/*
  * Page-locked host memory for read_frame buffers, so that the H2D copies of
  * vmaf_hip_extract_host_async really are asynchronous.  Replaces aligned_malloc for the frame
  * buffers of combo() (wrapper/src/combo.c:116-144, feature/src/common/alloc.h); 4096-byte aligned.
@@ -105,6 +126,7 @@ void vmaf_hip_host_free(void *p);
  */
 int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t row_stride_bytes);
 int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row_stride_bytes);
+int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int bytes_per_sample, size_t row_stride_bytes);
 
 /*
  * Batched nu-SVR RBF prediction.  Replaces the per-frame svm_predict() call site

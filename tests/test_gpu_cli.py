@@ -130,3 +130,19 @@ def test_truncated_and_missing_inputs(tmp_path):
     # --psnr is not part of this build: loud error, not a silent skip
     p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, model, "--psnr"], capture_output=True, text=True)
     assert p.returncode == 255 and "psnr" in p.stderr
+
+
+@pytest.mark.parametrize("name", ["default", "tenbit"])
+def test_raw_and_fp32_callbacks_give_identical_logs(name, tmp_path):
+    """vmafossexec hands raw luma to compute_vmaf_raw by default (GPU-side widening); VMAF_HIP_FP32_CALLBACK=1 keeps the
+    reference's fp32 read_frame contract.  Same frames, same numbers, to the last printed digit."""
+    case = EXEC[name]
+    rp, dp, w, h = _files(case, tmp_path)
+    logs = []
+    for env_val in ("0", "1"):
+        log = str(tmp_path / f"log{env_val}.json")
+        cmd = [OURS, case["fmt"], str(w), str(h), rp, dp, os.path.join(ROOT, case["model"]), "--log", log, "--log-fmt", "json"] + case["args"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, VMAF_HIP_FP32_CALLBACK=env_val))
+        assert p.returncode == 0, p.stderr + p.stdout
+        logs.append(json.load(open(log))["frames"])
+    assert logs[0] == logs[1] and len(logs[0]) == len(case["frames"])

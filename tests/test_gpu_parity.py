@@ -182,3 +182,40 @@ def test_error_paths(model_path):
     with vmaf_amd.Engine(64, 48) as e:
         with pytest.raises(vmaf_amd.VmafHipError, match="previous frame"):
             e.extract(ref, dis, continue_sequence=True)
+
+
+@pytest.mark.parametrize("bits,w,h", [(8, 160, 96), (8, 101, 75), (10, 192, 108), (10, 67, 50)])
+def test_raw_luma_ingest_is_bit_identical_to_fp32_ingest(bits, w, h):
+    """u8 / u16 luma uploaded as the file holds it and widened on the GPU (file_io.c:86-172 on the
+    device) gives the very same atoms as the fp32 planes a read_frame callback would have produced - vector path
+    (w % 4 == 0) and scalar path, several batches, and the raw motion halo."""
+    r, d = synth.make_clip(w, h, 5, bits=bits, seed=21 + w, cuts=(3,))
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    assert r.dtype == (np.uint8 if bits == 8 else np.uint16)
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:
+        want = e.extract(ref, dis)
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:
+        got = e.extract_raw(r, d)
+    assert np.array_equal(got, want)
+    with vmaf_amd.Engine(w, h, max_batch=4) as e:
+        e.motion_seed(r[1])                         # raw halo frame
+        shard = e.extract_raw(r[2:], d[2:], continue_sequence=True)
+    assert np.array_equal(shard, want[2:])
+    _check(got, oracle.clip_atoms(ref, dis, oracle.ORDER_AVX), f"raw {bits}-bit {w}x{h}")
+
+
+def test_raw_luma_device_pointers_and_errors():
+    torch = pytest.importorskip("torch")
+    r, d = synth.make_clip(128, 72, 3, seed=4)
+    with vmaf_amd.Engine(128, 72, max_batch=3) as e:
+        want = e.extract_raw(r, d)
+        tr, td = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+        torch.cuda.synchronize()
+        got = e.extract_device_raw(tr, td, 3, 1)
+        assert np.array_equal(got, want)
+        with pytest.raises(vmaf_amd.VmafHipError, match="uint8 or uint16"):
+            e.extract_raw(r.astype(np.int32), d.astype(np.int32))
+        out = np.zeros((1, 20))
+        assert e.L.vmaf_hip_extract_host_raw(e._h, r.ctypes.data, d.ctypes.data, 3, 128, 128 * 72, 1, 0,
+                                             out.ctypes.data_as(vmaf_amd.binding._dp)) != 0
+        assert "bytes_per_sample" in vmaf_amd.binding._err(e.L)

@@ -53,6 +53,10 @@ def load_library():
     for name in ("vmaf_hip_extract_device", "vmaf_hip_extract_host", "vmaf_hip_extract_device_async",
                  "vmaf_hip_extract_host_async"):
         getattr(L, name).argtypes = [vp, vp, vp, sz, sz, i, i, _dp]
+    for name in ("vmaf_hip_extract_device_raw", "vmaf_hip_extract_host_raw", "vmaf_hip_extract_device_raw_async",
+                 "vmaf_hip_extract_host_raw_async"):
+        getattr(L, name).argtypes = [vp, vp, vp, i, sz, sz, i, i, _dp]
+    L.vmaf_hip_motion_seed_host_raw.argtypes = [vp, vp, i, sz]
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_host_alloc.argtypes = [sz]
     L.vmaf_hip_host_alloc.restype = vp
@@ -125,6 +129,40 @@ class Engine:
             done += n
         return out
 
+    def extract_raw(self, ref, dis, continue_sequence=False):
+        """ref, dis: uint8 or uint16 numpy [F,h,w] luma as the YUV file holds it (uint16 = 10-bit words, scored
+        as value / 4.0); the widening to fp32 happens on the GPU.  -> atoms [F,20]."""
+        ref, dis = np.ascontiguousarray(ref), np.ascontiguousarray(dis)
+        if ref.dtype not in (np.uint8, np.uint16) or dis.dtype != ref.dtype:
+            raise VmafHipError(f"raw luma must be uint8 or uint16, got {ref.dtype}/{dis.dtype}")
+        if ref.ndim == 2:
+            ref, dis = ref[None], dis[None]
+        F, h, w = ref.shape
+        if (h, w) != (self.h, self.w) or dis.shape != ref.shape:
+            raise VmafHipError(f"shape {ref.shape}/{dis.shape} does not match engine {self.h}x{self.w}")
+        bps = ref.dtype.itemsize
+        out = np.zeros((F, N_ATOMS))
+        done = 0
+        while done < F:
+            n = min(self.max_batch, F - done)
+            if self.L.vmaf_hip_extract_host_raw(self._h, ref[done:].ctypes.data, dis[done:].ctypes.data, bps, w * bps, w * h * bps, n,
+                                                1 if (continue_sequence or done) else 0, out[done:].ctypes.data_as(_dp)):
+                raise VmafHipError(_err(self.L))
+            done += n
+        return out
+
+    def extract_device_raw(self, d_ref, d_dis, nframes, bytes_per_sample, continue_sequence=False, out=None):
+        """Device-resident raw luma (addresses or torch uint8 / int16 tensors), dense rows."""
+        pr = d_ref.data_ptr() if hasattr(d_ref, "data_ptr") else int(d_ref)
+        pd = d_dis.data_ptr() if hasattr(d_dis, "data_ptr") else int(d_dis)
+        rs = self.w * bytes_per_sample
+        if out is None:
+            out = np.zeros((nframes, N_ATOMS))
+        if self.L.vmaf_hip_extract_device_raw(self._h, pr, pd, bytes_per_sample, rs, rs * self.h, nframes,
+                                              1 if continue_sequence else 0, out.ctypes.data_as(_dp)):
+            raise VmafHipError(_err(self.L))
+        return out
+
     # -- device pointers (torch tensors or raw ints) ----------------------------------------------
     def extract_device(self, d_ref, d_dis, nframes, row_stride_bytes=None, frame_stride_bytes=None,
                        continue_sequence=False, out=None, sync=True):
@@ -147,7 +185,10 @@ class Engine:
 
     def motion_seed(self, ref_frame):
         """Blur one ref frame (numpy [h,w] float32, or a device address / torch tensor) as the motion halo."""
-        if hasattr(ref_frame, "data_ptr") or isinstance(ref_frame, int):
+        if isinstance(ref_frame, np.ndarray) and ref_frame.dtype in (np.uint8, np.uint16):
+            a = np.ascontiguousarray(ref_frame)
+            rc = self.L.vmaf_hip_motion_seed_host_raw(self._h, a.ctypes.data, a.dtype.itemsize, self.w * a.dtype.itemsize)
+        elif hasattr(ref_frame, "data_ptr") or isinstance(ref_frame, int):
             p = ref_frame.data_ptr() if hasattr(ref_frame, "data_ptr") else ref_frame
             rc = self.L.vmaf_hip_motion_seed_device(self._h, p, self.w * 4)
         else:

@@ -64,11 +64,19 @@ std::vector<int> parse_devices()
 // serially through read_frame into page-locked buffers and dealt, a batch at a time, round-robin to
 // the engines (one per GPU); each batch after the first gets its motion halo from the previous
 // batch's last ref frame.  Fills atoms [frames][20].
-void extract_atoms(int (*read_frame)(float *, float *, float *, int, void *), void *user_data, int w, int h,
-                   bool scalar_order, std::vector<double> &atoms)
+// Where the frames come from: the reference's fp32 callback (bps = 0), or a raw-luma callback that hands over the
+// samples as the file holds them (bps = 1 / 2 bytes) and leaves the widening to the GPU.
+struct FrameSource {
+    int bps = 0;
+    int (*read_frame)(float *, float *, float *, int, void *) = nullptr;
+    int (*read_raw)(void *, void *, int, void *) = nullptr;
+    void *user = nullptr;
+};
+
+void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, std::vector<double> &atoms)
 {
     if (w <= 0 || h <= 0) throw VmafException("wrong width " + std::to_string(w) + " or height " + std::to_string(h) + ".");
-    const size_t stride = ((size_t)w * 4 + 31) / 32 * 32;          // ALIGN_CEIL, combo.c:106
+    const size_t stride = src.bps ? (size_t)w * src.bps : ((size_t)w * 4 + 31) / 32 * 32;   // ALIGN_CEIL, combo.c:106
     const size_t plane = stride * h;
 
     const std::vector<int> devices = parse_devices();
@@ -116,7 +124,8 @@ void extract_atoms(int (*read_frame)(float *, float *, float *, int, void *), vo
         float *rb = s.ref[s.fill], *db = s.dis[s.fill];
         int n = 0;
         while (n < batch) {
-            const int ret = read_frame((float *)((char *)rb + plane * n), (float *)((char *)db + plane * n), temp, (int)stride, user_data);
+            const int ret = src.bps ? src.read_raw((char *)rb + plane * n, (char *)db + plane * n, (int)stride, src.user)
+                                    : src.read_frame((float *)((char *)rb + plane * n), (float *)((char *)db + plane * n), temp, (int)stride, src.user);
             if (ret == 1) throw VmafException("read_frame failed.");   // combo.c:151-153
             if (ret == 2) { eof = true; break; }
             ++n;
@@ -125,10 +134,13 @@ void extract_atoms(int (*read_frame)(float *, float *, float *, int, void *), vo
         collect(g);                                                // engine g is free again, its other buffer reusable
         const bool cont = total > 0;
         if (cont && G > 1) {
-            if (vmaf_hip_motion_seed_host(guard.engines[g], prev_last_ref, stride)) throw VmafException(vmaf_hip_last_error());
+            const int rc = src.bps ? vmaf_hip_motion_seed_host_raw(guard.engines[g], prev_last_ref, src.bps, stride)
+                                   : vmaf_hip_motion_seed_host(guard.engines[g], prev_last_ref, stride);
+            if (rc) throw VmafException(vmaf_hip_last_error());
         }
-        if (vmaf_hip_extract_host_async(guard.engines[g], rb, db, stride, plane, n, cont ? 1 : 0, s.out.data()))
-            throw VmafException(vmaf_hip_last_error());
+        const int rc = src.bps ? vmaf_hip_extract_host_raw_async(guard.engines[g], rb, db, src.bps, stride, plane, n, cont ? 1 : 0, s.out.data())
+                               : vmaf_hip_extract_host_async(guard.engines[g], rb, db, stride, plane, n, cont ? 1 : 0, s.out.data());
+        if (rc) throw VmafException(vmaf_hip_last_error());
         s.pending = true; s.pend_start = total; s.pend_n = n;
         s.fill ^= 1;
         prev_last_ref = (const float *)((const char *)rb + plane * (n - 1));
@@ -290,7 +302,7 @@ void write_logs(const char *log_path, const char *log_fmt, const char *model_pat
     std::fclose(fp);
 }
 
-double run_vmaf(const char *fmt, int width, int height, int (*read_frame)(float *, float *, float *, int, void *), void *user_data,
+double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
                 const char *model_path, const char *log_path, const char *log_fmt, bool disable_clip, bool disable_avx,
                 bool enable_transform, bool do_psnr, bool do_ssim, bool do_ms_ssim, const char *pool_method)
 {
@@ -299,7 +311,7 @@ double run_vmaf(const char *fmt, int width, int height, int (*read_frame)(float 
     if (do_psnr || do_ssim || do_ms_ssim)
         throw VmafException("psnr/ssim/ms_ssim are not features of this build (MI355X VMAF v0.6.1 hot path only)");
     if (!model_path) throw VmafException("Error loading model (.pkl): null path");
-    if (!read_frame) throw VmafException("read_frame callback is null");
+    if (!(src.bps ? (void *)src.read_raw : (void *)src.read_frame)) throw VmafException("read_frame callback is null");
 
     vmaf_amd::VmafModel model;
     try { model = vmaf_amd::load_vmaf_model(model_path); }
@@ -307,7 +319,7 @@ double run_vmaf(const char *fmt, int width, int height, int (*read_frame)(float 
 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> atoms;
-    extract_atoms(read_frame, user_data, width, height, disable_avx, atoms);
+    extract_atoms(src, width, height, disable_avx, atoms);
     const size_t F = atoms.size() / kAtoms;
     if (F == 0) throw VmafException("no frames delivered by read_frame");
     std::vector<double> vmaf;
@@ -340,8 +352,41 @@ double compute_vmaf(char *fmt, int width, int height, int (*read_frame)(float *,
                     int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method)
 {
     // disable_avx selects the reference's scalar summation order instead of its AVX order (libvmaf.cpp:56-61)
-    return run_vmaf(fmt, width, height, read_frame, user_data, model_path, log_path, log_fmt, disable_clip != 0, disable_avx != 0,
+    FrameSource src;
+    src.read_frame = read_frame; src.user = user_data;
+    return run_vmaf(fmt, width, height, src, model_path, log_path, log_fmt, disable_clip != 0, disable_avx != 0,
                     (enable_transform || phone_model), do_psnr != 0, do_ssim != 0, do_ms_ssim != 0, pool_method);
+}
+
+double compute_vmaf_raw(char *fmt, int width, int height, int (*read_frame_raw)(void *, void *, int, void *), void *user_data,
+                        char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform,
+                        int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method)
+{
+    FrameSource src;
+    const size_t n = fmt ? std::strlen(fmt) : 0;
+    src.bps = (n > 4 && std::strcmp(fmt + n - 4, "10le") == 0) ? 2 : 1;      // the *10le formats hold 16-bit words (file_io.c:137-172)
+    src.read_raw = read_frame_raw; src.user = user_data;
+    return run_vmaf(fmt, width, height, src, model_path, log_path, log_fmt, disable_clip != 0, disable_avx != 0,
+                    (enable_transform || phone_model), do_psnr != 0, do_ssim != 0, do_ms_ssim != 0, pool_method);
+}
+
+int compute_vmaf_raw_noexcept(double *score, char *fmt, int width, int height, int (*read_frame_raw)(void *, void *, int, void *),
+                              void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx,
+                              int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method,
+                              char *errbuf, int errbuf_len)
+{
+    try {
+        const double s = compute_vmaf_raw(fmt, width, height, read_frame_raw, user_data, model_path, log_path, log_fmt, disable_clip,
+                                          disable_avx, enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, pool_method);
+        if (score) *score = s;
+        return 0;
+    } catch (const std::exception &e) {
+        copy_err(errbuf, errbuf_len, e.what());
+        return 1;
+    } catch (...) {
+        copy_err(errbuf, errbuf_len, "unknown error");
+        return 1;
+    }
 }
 
 int compute_vmaf_noexcept(double *score, char *fmt, int width, int height, int (*read_frame)(float *, float *, float *, int, void *),

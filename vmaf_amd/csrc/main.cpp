@@ -65,6 +65,20 @@ int read_frame_cb(float *ref_data, float *dis_data, float *temp_data, int stride
     return 0;
 }
 
+// The same frame rule with raw hand-over (compute_vmaf_raw): the luma plane goes to the library as the file holds it,
+// the GPU does file_io.c's conversion.  One fread per plane.
+int read_frame_raw_cb(void *ref_luma, void *dis_luma, int stride_byte, void *user)
+{
+    YuvPair &s = *(YuvPair *)user;
+    const size_t bytes = (size_t)stride_byte * s.height;
+    if (std::fread(ref_luma, 1, bytes, s.ref) != bytes) return std::feof(s.ref) ? 2 : 1;
+    if (std::fread(dis_luma, 1, bytes, s.dis) != bytes) return std::feof(s.dis) ? 2 : 1;
+    s.row.resize(1 << 20);
+    skip_chroma(s.ref, s, (float *)s.row.data(), s.row.size());
+    skip_chroma(s.dis, s, (float *)s.row.data(), s.row.size());
+    return 0;
+}
+
 const char *opt_value(char **b, char **e, const std::string &name)
 {
     char **it = std::find(b, e, name);
@@ -128,8 +142,13 @@ int main(int argc, char *argv[])
     else if (!(s.dis = std::fopen(dis_path, "rb"))) { std::fprintf(stderr, "fopen ref_path %s failed.\n", dis_path); ret = 1; }
     if (!ret) {
         try {
-            compute_vmaf(fmt, width, height, read_frame_cb, &s, model_path, (char *)log_path, (char *)log_fmt, disable_clip, disable_avx,
-                         enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
+            const char *fp32 = std::getenv("VMAF_HIP_FP32_CALLBACK");      // 1: the reference's fp32 read_frame contract instead
+            if (fp32 && *fp32 && *fp32 != '0')
+                compute_vmaf(fmt, width, height, read_frame_cb, &s, model_path, (char *)log_path, (char *)log_fmt, disable_clip, disable_avx,
+                             enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
+            else
+                compute_vmaf_raw(fmt, width, height, read_frame_raw_cb, &s, model_path, (char *)log_path, (char *)log_fmt, disable_clip,
+                                 disable_avx, enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
         } catch (const std::exception &e) {
             std::fprintf(stderr, "Error: %s\n", e.what());
             usage(argv[0]);

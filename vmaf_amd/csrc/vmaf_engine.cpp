@@ -70,6 +70,7 @@ struct vmaf_hip_engine {
     int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
     float *vif_ref[4] = {}, *vif_dis[4] = {};   // [1..3]
     float *adm_ref[4] = {}, *adm_dis[4] = {};   // [1..3] = LL of level 0..2
+    unsigned char *raw_ref = nullptr, *raw_dis = nullptr;   // device copies of raw 8/16-bit luma (allocated on first use)
     float *carry[2] = {};
     int carry_cur = 0;
     bool carry_valid = false;
@@ -301,6 +302,7 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     }
     (void)hipFree(e->carry[0]); (void)hipFree(e->carry[1]);
     (void)hipFree(e->stage_ref); (void)hipFree(e->stage_dis);
+    (void)hipFree(e->raw_ref); (void)hipFree(e->raw_dis);
     (void)hipFree(e->partials); (void)hipFree(e->sums_dev);
     if (e->sums_host) (void)hipHostFree(e->sums_host);
     hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_t0, e->ev_t1, e->ev_k0, e->ev_k1 };
@@ -376,6 +378,96 @@ int vmaf_hip_extract_host(vmaf_hip_engine *e, const float *h_ref, const float *h
     if (vmaf_hip_extract_host_async(e, h_ref, h_dis, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence, atoms_out))
         return 1;
     return vmaf_hip_engine_sync(e);
+}
+
+// ---- raw 8/16-bit luma in, widened on the device (file_io.c:86-172) ----
+
+static int check_raw(vmaf_hip_engine *e, int bytes_per_sample, size_t row_stride_bytes, size_t frame_stride_bytes, int nframes)
+{
+    if (bytes_per_sample != 1 && bytes_per_sample != 2) return fail("bytes_per_sample %d is neither 1 nor 2", bytes_per_sample);
+    if (row_stride_bytes < (size_t)e->w * bytes_per_sample) return fail("row stride %zu smaller than a row", row_stride_bytes);
+    if (row_stride_bytes % bytes_per_sample || frame_stride_bytes % bytes_per_sample) return fail("strides must be multiples of the sample size");
+    if (nframes > 1 && frame_stride_bytes < row_stride_bytes * e->h) return fail("frame stride smaller than a frame");
+    return 0;
+}
+
+static int widen_and_enqueue(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bps, size_t rs, size_t fs, int nframes,
+                             int continue_sequence, double *atoms_out)
+{
+    HIP_TRY(vk_launch_widen(d_ref, bps, rs, fs, e->stage_ref, e->w, e->h, nframes, e->s_main));
+    HIP_TRY(vk_launch_widen(d_dis, bps, rs, fs, e->stage_dis, e->w, e->h, nframes, e->s_main));
+    const size_t dense_row = (size_t)e->w * 4, dense_frame = dense_row * e->h;
+    if (enqueue_batch(e, e->stage_ref, e->stage_dis, dense_row, dense_frame, nframes, continue_sequence)) return 1;
+    e->pend_frames = nframes;
+    e->pend_first_has_motion = continue_sequence != 0;
+    e->pend_out = atoms_out;
+    return 0;
+}
+
+int vmaf_hip_extract_device_raw_async(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bytes_per_sample,
+                                      size_t row_stride_bytes, size_t frame_stride_bytes, int nframes, int continue_sequence,
+                                      double *atoms_out)
+{
+    if (check_call(e, d_ref, d_dis, nframes, atoms_out)) return 1;
+    if (check_raw(e, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes)) return 1;
+    return widen_and_enqueue(e, d_ref, d_dis, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence, atoms_out);
+}
+
+int vmaf_hip_extract_host_raw_async(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample,
+                                    size_t row_stride_bytes, size_t frame_stride_bytes, int nframes, int continue_sequence,
+                                    double *atoms_out)
+{
+    if (check_call(e, h_ref, h_dis, nframes, atoms_out)) return 1;
+    if (check_raw(e, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes)) return 1;
+    const size_t dense_row = (size_t)e->w * bytes_per_sample, dense_frame = dense_row * e->h;
+    if (!e->raw_ref) {
+        const size_t bytes = (size_t)e->max_batch * e->w * e->h * 2;
+        if (hipMalloc((void **)&e->raw_ref, bytes) != hipSuccess || hipMalloc((void **)&e->raw_dis, bytes) != hipSuccess)
+            return fail("hipMalloc(raw luma staging, 2 x %zu bytes) failed", bytes);
+    }
+    if (row_stride_bytes == dense_row && (nframes == 1 || frame_stride_bytes == dense_frame)) {
+        HIP_TRY(hipMemcpyAsync(e->raw_ref, h_ref, dense_frame * nframes, hipMemcpyHostToDevice, e->s_main));
+        HIP_TRY(hipMemcpyAsync(e->raw_dis, h_dis, dense_frame * nframes, hipMemcpyHostToDevice, e->s_main));
+    } else {
+        for (int f = 0; f < nframes; ++f) {
+            const char *sr = (const char *)h_ref + (size_t)f * frame_stride_bytes, *sd = (const char *)h_dis + (size_t)f * frame_stride_bytes;
+            HIP_TRY(hipMemcpy2DAsync(e->raw_ref + f * dense_frame, dense_row, sr, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+            HIP_TRY(hipMemcpy2DAsync(e->raw_dis + f * dense_frame, dense_row, sd, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+        }
+    }
+    return widen_and_enqueue(e, e->raw_ref, e->raw_dis, bytes_per_sample, dense_row, dense_frame, nframes, continue_sequence, atoms_out);
+}
+
+int vmaf_hip_extract_host_raw(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample, size_t row_stride_bytes,
+                              size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
+{
+    if (vmaf_hip_extract_host_raw_async(e, h_ref, h_dis, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes,
+                                        continue_sequence, atoms_out))
+        return 1;
+    return vmaf_hip_engine_sync(e);
+}
+
+int vmaf_hip_extract_device_raw(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bytes_per_sample, size_t row_stride_bytes,
+                                size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
+{
+    if (vmaf_hip_extract_device_raw_async(e, d_ref, d_dis, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes,
+                                          continue_sequence, atoms_out))
+        return 1;
+    return vmaf_hip_engine_sync(e);
+}
+
+int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int bytes_per_sample, size_t row_stride_bytes)
+{
+    if (!e || !h_ref) return fail("null argument");
+    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (check_raw(e, bytes_per_sample, row_stride_bytes, 0, 1)) return 1;
+    HIP_TRY(hipSetDevice(e->device));
+    // the float staging plane doubles as the landing area of the raw rows (its tail) - one frame only
+    const size_t dense_row = (size_t)e->w * bytes_per_sample;
+    unsigned char *tmp = (unsigned char *)(e->stage_dis);
+    HIP_TRY(hipMemcpy2DAsync(tmp, dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+    HIP_TRY(vk_launch_widen(tmp, bytes_per_sample, dense_row, dense_row * e->h, e->stage_ref, e->w, e->h, 1, e->s_main));
+    return vmaf_hip_motion_seed_device(e, e->stage_ref, (size_t)e->w * 4);
 }
 
 void *vmaf_hip_host_alloc(size_t bytes)

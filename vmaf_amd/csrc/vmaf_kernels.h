@@ -41,6 +41,9 @@ hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, si
                                double *partial, hipStream_t s);
 hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
                             const float *carry_in, float *carry_out, double *partial, hipStream_t s);
+// raw luma (1 or 2 bytes per sample, 2 = little-endian words / 4.0) -> dense fp32 planes [nframes][h][w]
+hipError_t vk_launch_widen(const void *src, int bytes_per_sample, size_t src_row_bytes, size_t src_frame_bytes, float *dst,
+                           int w, int h, int nframes, hipStream_t s);
 hipError_t vk_launch_reduce(const double *partial, const vk_reduce_table *tab, int nframes, double *sums, hipStream_t s);
 hipError_t vk_launch_svm(const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho, const double *x,
                          int n, double *out, hipStream_t s);

@@ -826,6 +826,34 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
     }
 }
 
+// ---------------------------------------------------------------- raw luma ingest
+// file_io.c:86-172 on the device: 8-bit samples -> (float)px, 16-bit little-endian words -> (float)px / 4.0
+// (exact: a power of two; no masking to 10 bits, as in the reference), dense fp32 planes out.  The -128 offset
+// stays where it is for fp32 input: in the loads of the feature kernels.  Four samples per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void widen_kernel(const unsigned char *__restrict__ src, size_t src_row_bytes, size_t src_frame_bytes,
+                                                    float *__restrict__ dst, int w, int h, int vec_ok)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w) return;
+    const T *row = reinterpret_cast<const T *>(src + (size_t)blockIdx.z * src_frame_bytes + (size_t)y * src_row_bytes);
+    float *out = dst + ((size_t)blockIdx.z * h + y) * w;
+    const float scale = sizeof(T) == 2 ? 0.25f : 1.0f;
+    if (vec_ok && x4 + 4 <= w) {
+        float4 v;
+        if (sizeof(T) == 1) {
+            const uchar4 p = *reinterpret_cast<const uchar4 *>(row + x4);
+            v = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+        } else {
+            const ushort4 p = *reinterpret_cast<const ushort4 *>(row + x4);
+            v = make_float4((float)p.x * scale, (float)p.y * scale, (float)p.z * scale, (float)p.w * scale);
+        }
+        *reinterpret_cast<float4 *>(out + x4) = v;
+    } else {
+        for (int x = x4; x < min(x4 + 4, w); ++x) out[x] = (float)row[x] * scale;
+    }
+}
+
 // ---------------------------------------------------------------- final reduction
 __global__ __launch_bounds__(256) void reduce_kernel(const double *__restrict__ partial, vk_reduce_table tab,
                                                      double *__restrict__ sums /* [frame][VK_NSUMS] */)
@@ -938,6 +966,20 @@ hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, in
         motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
     else
         motion_kernel<ORDER_AVX><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_widen(const void *src, int bytes_per_sample, size_t src_row_bytes, size_t src_frame_bytes, float *dst,
+                           int w, int h, int nframes, hipStream_t s)
+{
+    const dim3 g((w + 1023) / 1024, h, nframes);
+    const size_t a = (size_t)4 * bytes_per_sample;                    // alignment of a 4-sample vector load
+    const int vec_ok = w % 4 == 0 && reinterpret_cast<uintptr_t>(src) % a == 0 && src_row_bytes % a == 0 && src_frame_bytes % a == 0 &&
+                       reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+    if (bytes_per_sample == 1)
+        widen_kernel<unsigned char><<<g, 256, 0, s>>>((const unsigned char *)src, src_row_bytes, src_frame_bytes, dst, w, h, vec_ok);
+    else
+        widen_kernel<unsigned short><<<g, 256, 0, s>>>((const unsigned char *)src, src_row_bytes, src_frame_bytes, dst, w, h, vec_ok);
     return hipGetLastError();
 }
 
