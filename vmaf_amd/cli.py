@@ -146,9 +146,10 @@ class Result:
 
 
 # ---------------------------------------------------------------------------------- scoring
-def read_luma(path, fmt, width, height):
-    """Memory-map a raw YUV file and return the luma planes [F,h,w] as float32 in 8-bit units
-    (feature/src/common/file_io.c:86-172: 10-bit / 4.0), skipping chroma (frame.c:80-124)."""
+def read_luma(path, fmt, width, height, raw=False):
+    """Memory-map a raw YUV file and return the luma planes [F,h,w], skipping chroma (frame.c:80-124): as float32 in
+    8-bit units (feature/src/common/file_io.c:86-172: 10-bit / 4.0), or with raw=True as the uint8 / uint16 samples
+    themselves, for the GPU to widen (Engine.extract_raw)."""
     ten = fmt.endswith('10le')
     n = width * height
     chroma = {'yuv420p': n // 2, 'yuv422p': n, 'yuv444p': 2 * n}[fmt.replace('10le', '')]
@@ -159,10 +160,13 @@ def read_luma(path, fmt, width, height):
     if frames * frame_samples < total and total - frames * frame_samples >= n:
         frames += 1                                    # a last frame with short chroma is still scored (frame.c:83-87)
     mm = np.memmap(path, dtype=dt, mode='r')
-    out = np.empty((frames, height, width), np.float32)
+    out = np.empty((frames, height, width), (np.uint16 if ten else np.uint8) if raw else np.float32)
     for f in range(frames):
         y = np.asarray(mm[f * frame_samples:f * frame_samples + n]).reshape(height, width)
-        out[f] = (y.astype(np.float64) / 4.0).astype(np.float32) if ten else y.astype(np.float32)
+        if raw:
+            out[f] = y
+        else:
+            out[f] = (y.astype(np.float64) / 4.0).astype(np.float32) if ten else y.astype(np.float32)
     return out
 
 
@@ -170,8 +174,8 @@ def score_asset(asset, model_path, phone_model, device=0, engine_cache=None):
     """-> Result.  The feature + fusion hot path on the GPU; no CPU fallback."""
     from . import binding
     w, h, fmt = asset.asset_dict['width'], asset.asset_dict['height'], asset.asset_dict['yuv_type']
-    ref = read_luma(asset.ref_path, fmt, w, h)
-    dis = read_luma(asset.dis_path, fmt, w, h)
+    ref = read_luma(asset.ref_path, fmt, w, h, raw=True)
+    dis = read_luma(asset.dis_path, fmt, w, h, raw=True)
     frames = min(len(ref), len(dis))
     key = (w, h, device)
     eng = engine_cache.get(key) if engine_cache is not None else None
@@ -180,7 +184,7 @@ def score_asset(asset, model_path, phone_model, device=0, engine_cache=None):
         eng = binding.Engine(w, h, max_batch=batch, device=device)
         if engine_cache is not None:
             engine_cache[key] = eng
-    atoms = eng.extract(ref[:frames], dis[:frames])
+    atoms = eng.extract_raw(ref[:frames], dis[:frames])
     model_path = model_path or binding.DEFAULT_MODEL
     names = _model_feature_names(model_path)
     vm, feats = binding.predict_from_atoms(atoms, model_path, enable_transform=phone_model, device=device,
