@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +111,8 @@ def main():
     torch.cuda.synchronize()
 
     eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank)
+    if args.metrics:
+        eng.L.vmaf_hip_engine_enable_metrics(eng._h, 1, 1, 1, 0)
     atoms = np.zeros((K, B, 20))
     scratch = np.zeros((B, 20))
     for i in range(args.warmup):
@@ -163,7 +166,8 @@ def main():
         line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",
                 "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "synthetic 1920x1080 yuv420p 8-bit ref/dis pair, vmaf_v0.6.1, fp32 luma resident in HBM",
+                "config": {"workload": "synthetic 1920x1080 yuv420p 8-bit ref/dis pair, vmaf_v0.6.1, fp32 luma resident in HBM" +
+                                       (" + psnr/ssim/ms_ssim" if args.metrics else ""),
                            "frames_per_step_per_gpu": B, "frames_total": frames,
                            "parallelism": f"frame-range x{world}, 1-frame motion halo" if world > 1 else "single GPU"},
                 "mean_vmaf": round(float(np.mean(vmaf)), 4), "roofline": roof}

@@ -17,7 +17,8 @@
  *   disable_avx    0: sum the filter taps in the order of the reference's AVX kernels (its default on x86);
  *                  non-zero: in the order of its scalar loops (libvmaf.cpp:56-61) - both reproduced bit for bit
  *   enable_transform | phone_model   apply the model's score_transform (libvmaf.cpp:37-39)
- *   do_psnr / do_ssim / do_ms_ssim   not features of vmaf_v0.6.1 and not built here: non-zero is an error
+ *   do_psnr / do_ssim / do_ms_ssim   add the per-frame metrics psnr / ssim / ms_ssim to the logs (combo.c:168-230,
+ *                  vmaf.cpp:595-597), computed on the GPU next to the VMAF features (vmaf_hip_engine_enable_metrics)
  *   pool_method    NULL | "mean" | "min" | "harmonic_mean"
  * Returns the pooled VMAF score.  Failures are reported as in the reference, by a C++ exception
  * derived from std::exception (wrapper/src/vmaf.h:144-151) that wrapper/src/main.cpp:219-230 catches.

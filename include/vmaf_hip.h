@@ -129,6 +129,19 @@ int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row
 int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int bytes_per_sample, size_t row_stride_bytes);
 
 /*
+ * Optional per-frame metrics of the reference's frame loop (wrapper/src/combo.c:168-230): PSNR
+ * (feature/src/psnr.c:37-61), SSIM (feature/src/ssim.c:52-182) and MS-SSIM (feature/src/ms_ssim.c:118-326), computed
+ * on the planes as given (before the -128 offset), on their own stream next to the VMAF features.  ten_bit selects
+ * the PSNR peak and cap (255.75 / 72 instead of 255 / 60, combo.c:171-186).  Call before the first extract, or between
+ * synchronised calls.  SSIM at decimation factor 1 (min(w,h) < 384) and MS-SSIM need dense input planes.
+ * vmaf_hip_engine_get_metrics copies the metrics of the frames of the last synchronised extract call:
+ * out[nframes][VMAF_HIP_METRICS] = psnr, ssim, ms_ssim (0 where not enabled).
+ */
+#define VMAF_HIP_METRICS 3
+int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit);
+int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes);
+
+/*
  * Batched nu-SVR RBF prediction.  Replaces the per-frame svm_predict() call site
  * wrapper/src/vmaf.cpp:468 (wrapper/src/svm.cpp:305 -> :229 -> k_function RBF :179-219):
  *   out[f] = sum_i coef[i] * exp(-gamma * |x[f] - sv[i]|^2) - rho        (all fp64)

@@ -37,8 +37,8 @@ def lib():
     global _lib
     if _lib is None:
         so = os.path.join(HERE, "liboracle.so")
-        src = os.path.join(HERE, "vmaf_oracle.c")
-        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        srcs = [os.path.join(HERE, f) for f in ("vmaf_oracle.c", "iqa_oracle.c")]
+        if not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
             subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
         L = C.CDLL(so)
         L.oracle_conv_sep.argtypes = [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -54,6 +54,11 @@ def lib():
         L.oracle_adm_csf_rfactors.argtypes = [_fp]
         L.oracle_log2f_approx.argtypes = [C.c_float]
         L.oracle_log2f_approx.restype = C.c_float
+        L.oracle_psnr.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.oracle_psnr.restype = C.c_double
+        L.oracle_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _dp]
+        L.oracle_ms_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _dp, _dp]
+        L.oracle_ssim_scale.argtypes = [C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -73,6 +78,10 @@ def ref_lib():
             R.convolution_f32_c_s.argtypes = [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
             R.convolution_f32_c_s.restype = None
             R.ref_set_cpu.argtypes = [C.c_int]
+            if hasattr(R, "compute_psnr"):
+                R.compute_psnr.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_double]
+                R.compute_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+                R.compute_ms_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
             _ref = R
     return _ref
 
@@ -272,3 +281,67 @@ def ref_svm_predict(model_file, x):
         nodes[x.shape[1]].index = -1                             # terminator, vmaf.cpp:385-389
         out[f] = S.svm_predict(m, nodes)
     return out
+
+
+# ---------------------------------------------------------------- optional metrics (psnr.c, ssim.c, ms_ssim.c)
+def _peak(bits):
+    return (255.0, 60.0) if bits == 8 else (255.75, 72.0)          # combo.c:171-186
+
+
+def psnr(ref_raw, dis_raw, bits=8):
+    r, d = _f32(ref_raw), _f32(dis_raw)
+    h, w = r.shape
+    return lib().oracle_psnr(_ptr(r), _ptr(d), w, h, w, *_peak(bits))
+
+
+def ssim(ref_raw, dis_raw):
+    """-> (ssim, l, c, s)"""
+    r, d = _f32(ref_raw), _f32(dis_raw)
+    h, w = r.shape
+    out = np.zeros(4)
+    if lib().oracle_ssim(_ptr(r), _ptr(d), w, h, w, out.ctypes.data_as(_dp)):
+        raise ValueError("image too small for the SSIM window after decimation")
+    return tuple(out)
+
+
+def ms_ssim(ref_raw, dis_raw):
+    """-> (ms_ssim, lcs[15])"""
+    r, d = _f32(ref_raw), _f32(dis_raw)
+    h, w = r.shape
+    s = C.c_double()
+    lcs = np.zeros(15)
+    if lib().oracle_ms_ssim(_ptr(r), _ptr(d), w, h, w, C.byref(s), lcs.ctypes.data_as(_dp)):
+        raise ValueError("scale below 1x1")
+    return s.value, lcs
+
+
+def ref_psnr(ref_raw, dis_raw, bits=8):
+    R = ref_lib()
+    r, sb = _padded(ref_raw)
+    d, _ = _padded(dis_raw)
+    h, w = np.asarray(ref_raw).shape
+    s = C.c_double()
+    assert R.compute_psnr(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(s), *_peak(bits)) == 0
+    return s.value
+
+
+def ref_ssim(ref_raw, dis_raw):
+    R = ref_lib()
+    r, sb = _padded(ref_raw)
+    d, _ = _padded(dis_raw)
+    h, w = np.asarray(ref_raw).shape
+    v = [C.c_double() for _ in range(4)]
+    assert R.compute_ssim(_ptr(r), _ptr(d), w, h, sb, sb, *[C.byref(x) for x in v]) == 0
+    return tuple(x.value for x in v)
+
+
+def ref_ms_ssim(ref_raw, dis_raw):
+    R = ref_lib()
+    r, sb = _padded(ref_raw)
+    d, _ = _padded(dis_raw)
+    h, w = np.asarray(ref_raw).shape
+    s = C.c_double()
+    l, c, st = np.zeros(5), np.zeros(5), np.zeros(5)
+    assert R.compute_ms_ssim(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(s), l.ctypes.data_as(_dp), c.ctypes.data_as(_dp),
+                             st.ctypes.data_as(_dp)) == 0
+    return s.value, np.concatenate([l, c, st])

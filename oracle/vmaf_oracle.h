@@ -60,6 +60,14 @@ void oracle_adm_csf_rfactors(float out[8]);
 /* vif_tools.c:46-75 */
 float oracle_log2f_approx(float x);
 
+/* ---- optional per-frame metrics (oracle/iqa_oracle.c): psnr.c, ssim.c, ms_ssim.c, iqa/ ---- */
+double oracle_psnr(const float *ref, const float *dis, int w, int h, int stride, double peak, double psnr_max);
+int oracle_ssim_scale(int w, int h);
+int oracle_ssim(const float *ref, const float *cmp, int w, int h, int stride, double out[4]);           /* ssim, l, c, s */
+int oracle_ms_ssim(const float *ref, const float *cmp, int w, int h, int stride, double *score, double *out_lcs /* 15 or NULL */);
+const float *oracle_ssim_window(void);      /* 11 taps */
+const float *oracle_ms_ssim_lpf(void);      /* 9 x 9 */
+
 #ifdef __cplusplus
 }
 #endif

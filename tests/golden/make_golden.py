@@ -54,6 +54,10 @@ EXEC = {
     "motion2_model": ("c64x48", "yuv420p", "tests/golden/models/test_motion2.pkl", []),
     "norm_none": ("c64x48", "yuv420p", "tests/golden/models/nflxtrain_norm_type_none.pkl", []),
     "vmafv4": ("c64x48", "yuv420p", "tests/golden/models/nflxall_vmafv4.pkl", []),
+    # optional per-frame metrics (combo.c:168-230): what the Python VmafossExecQualityRunner always asks for
+    "metrics": ("c576x324_cut", "yuv420p", "model/vmaf_v0.6.1.pkl", ["--psnr", "--ssim", "--ms-ssim"]),
+    "metrics_tenbit": ("c320x180_10bit", "yuv420p10le", "model/vmaf_v0.6.1.pkl", ["--psnr", "--ssim", "--ms-ssim"]),
+    "psnr_only": ("c64x48", "yuv420p", "model/vmaf_v0.6.1.pkl", ["--psnr"]),
 }
 IMAGES = ["100007", "100039"]      # python/test/resource/test_image_yuv/<n>.yuv vs <n>_noisy.yuv, 481x321 yuv444p
 

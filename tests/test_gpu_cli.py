@@ -74,7 +74,7 @@ def test_vmafossexec_matches_reference_outputs(name, tmp_path):
     _check_against_golden(stdout, xml, case)
 
 
-@pytest.mark.parametrize("name", ["default", "tenbit", "image_100007"])
+@pytest.mark.parametrize("name", ["default", "tenbit", "image_100007", "metrics", "metrics_tenbit"])
 def test_reference_main_runs_on_this_library(name, tmp_path):
     """Drop-in proof: the reference's wrapper/src/main.cpp + common/frame.c, unmodified, on libvmaf_amd.so."""
     if not os.path.exists(DROPIN):
@@ -127,9 +127,13 @@ def test_truncated_and_missing_inputs(tmp_path):
     # unknown model -> exception text + usage, exit -1 (main.cpp:225-230)
     p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, "/nonexistent.pkl"], capture_output=True, text=True)
     assert p.returncode == 255 and "Error: Error loading model (.pkl)" in p.stderr and "Usage:" in p.stderr
-    # --psnr is not part of this build: loud error, not a silent skip
-    p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, model, "--psnr"], capture_output=True, text=True)
-    assert p.returncode == 255 and "psnr" in p.stderr
+    # --ms-ssim on a frame too small for five scales: the reference fails in compute_ms_ssim ("scale below 1x1",
+    # ms_ssim.c:172-177 -> combo error -> exception -> exit -1); here the same message, loudly, not a silent skip
+    r, d = synth.make_clip(64, 48, 1, seed=1)
+    synth.write_yuv(rp, r, "yuv420p")
+    synth.write_yuv(dp, d, "yuv420p")
+    p = subprocess.run([OURS, "yuv420p", "64", "48", rp, dp, model, "--ms-ssim"], capture_output=True, text=True)
+    assert p.returncode == 255 and "scale below 1x1" in p.stderr
 
 
 @pytest.mark.parametrize("name", ["default", "tenbit"])

@@ -177,8 +177,8 @@ def test_error_paths(model_path):
     ref, dis = _clip(64, 48, 1)
     with pytest.raises(vmaf_amd.VmafHipError, match="model"):
         vmaf_amd.compute_vmaf_from_arrays(ref, dis, model_path="/nonexistent.pkl")
-    with pytest.raises(vmaf_amd.VmafHipError, match="psnr"):
-        vmaf_amd.compute_vmaf_from_arrays(ref, dis, model_path=model_path, do_psnr=True)
+    with pytest.raises(vmaf_amd.VmafHipError, match="scale below 1x1"):       # ms_ssim.c:172-177 on a 64x48 frame
+        vmaf_amd.compute_vmaf_from_arrays(ref, dis, model_path=model_path, do_ms_ssim=True)
     with vmaf_amd.Engine(64, 48) as e:
         with pytest.raises(vmaf_amd.VmafHipError, match="previous frame"):
             e.extract(ref, dis, continue_sequence=True)
@@ -219,3 +219,40 @@ def test_raw_luma_device_pointers_and_errors():
         assert e.L.vmaf_hip_extract_host_raw(e._h, r.ctypes.data, d.ctypes.data, 3, 128, 128 * 72, 1, 0,
                                              out.ctypes.data_as(vmaf_amd.binding._dp)) != 0
         assert "bytes_per_sample" in vmaf_amd.binding._err(e.L)
+
+
+@pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 1280, 720), (10, 577, 325), (8, 200, 180), (8, 1920, 1080)])
+def test_psnr_ssim_ms_ssim_match_oracle(bits, w, h):
+    """the optional per-frame metrics of combo.c:168-230 (psnr.c, ssim.c, ms_ssim.c) on the GPU against
+    the C restatement (itself bit-exact against the compiled reference, tests/test_oracle_vs_ref.py).  Covers SSIM
+    decimation factors 1, 3 and 4, odd sizes and the 10-bit PSNR peak.  Reference test tolerance: places=4."""
+    frames = 2 if w >= 1280 else 3
+    r, d = synth.make_clip(w, h, frames, bits=bits, seed=50 + w)
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:
+        e.enable_metrics(ten_bit=bits == 10)
+        atoms = e.extract(ref, dis)
+        got = e.metrics.copy()
+        e.extract_raw(r, d)
+        assert np.array_equal(e.metrics, got)          # raw ingest: same planes, same metrics
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:      # the metrics do not disturb the VMAF atoms
+        assert np.array_equal(e.extract(ref, dis), atoms)
+    assert got.shape == (frames, 3)
+    for f in range(frames):
+        want = (oracle.psnr(ref[f], dis[f], bits), oracle.ssim(ref[f], dis[f])[0], oracle.ms_ssim(ref[f], dis[f])[0])
+        assert abs(got[f, 0] - want[0]) < 1e-9, (f, got[f], want)
+        assert abs(got[f, 1] - want[1]) < 1e-6, (f, got[f], want)
+        assert abs(got[f, 2] - want[2]) < 1e-6, (f, got[f], want)
+
+
+def test_metrics_identical_frames_and_too_small_frames():
+    ref, _ = _clip(192, 180, 2, seed=8)
+    with vmaf_amd.Engine(192, 180) as e:
+        e.enable_metrics()
+        e.extract(ref, ref)
+        assert np.all(e.metrics[:, 0] == 60.0)         # psnr cap for 8-bit (psnr.c:54, combo.c:174)
+        assert np.allclose(e.metrics[:, 1:], 1.0, atol=1e-6)
+    with vmaf_amd.Engine(160, 96) as e:                # 96 -> 48 -> 24 -> 12 -> 6 < 11: "scale below 1x1" (ms_ssim.c:172-177)
+        with pytest.raises(vmaf_amd.VmafHipError, match="scale below 1x1"):
+            e.enable_metrics()
+        e.enable_metrics(ms_ssim=False)

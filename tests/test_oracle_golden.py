@@ -82,10 +82,15 @@ def test_fusion_oracle_matches_reference_vmafossexec(name):
     transform = "--phone-model" in case["args"] or "--enable-transform" in case["args"]
     vm, feats = oracle.vmaf_from_atoms(atoms, pkl, svm, enable_transform=transform, disable_clip="--disable-clip" in case["args"])
     assert len(vm) == len(case["frames"])
+    bits = 8 if case["clip"].startswith("images/") else ATOMS[case["clip"]]["params"].get("bits", 8)
+    metric = {"psnr": lambda a, b: oracle.psnr(a, b, bits), "ssim": lambda a, b: oracle.ssim(a, b)[0],
+              "ms_ssim": lambda a, b: oracle.ms_ssim(a, b)[0]}      # --psnr / --ssim / --ms-ssim columns (combo.c:168-230)
     for i, fr in enumerate(case["frames"]):
         assert _sig6(vm[i], fr["vmaf"]), (i, vm[i], fr["vmaf"])
         for k, v in fr.items():
-            if k not in ("frameNum", "vmaf"):
+            if k in metric:
+                assert _sig6(metric[k](ref[i], dis[i]), v), (k, i, v)
+            elif k not in ("frameNum", "vmaf"):
                 assert _sig6(feats[k][i], v), (k, i, feats[k][i], v)
     # "%f" on stdout; 2e-5 covers the exact-division vs rcpss+Newton difference in adm (<= 3e-7 relative)
     assert abs(pool(vm, case["pool"]) - case["stdout_score"]) < 2e-5

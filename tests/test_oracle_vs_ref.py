@@ -48,3 +48,16 @@ def test_csf_factors_match_survey_values():
     # evaluated 1/Q values
     want = [0.0173815, 0.00589069, 0.0319848, 0.0142991, 0.0433727, 0.0243969, 0.0456734, 0.0313127]
     assert np.allclose(oracle.csf_rfactors(), want, rtol=2e-6)
+
+
+@pytest.mark.parametrize("w,h,bits", [(576, 324, 8), (200, 180, 8), (577, 325, 10), (1280, 720, 8), (1083, 769, 8)])
+def test_psnr_ssim_ms_ssim_bit_exact(w, h, bits):
+    """oracle/iqa_oracle.c against psnr.c / ssim.c / ms_ssim.c + iqa/ compiled from the reference: SSIM decimation
+    factors 1, 3 (720p, odd-sized kernel) and 3 on odd dimensions (sw = w/f + (w&1)), the 10-bit PSNR peak."""
+    r, d = synth.make_clip(w, h, 1, bits=bits, seed=w + h)
+    r, d = synth.to_luma_f32(r, bits)[0], synth.to_luma_f32(d, bits)[0]
+    assert oracle.psnr(r, d, bits) == oracle.ref_psnr(r, d, bits)
+    assert oracle.ssim(r, d) == oracle.ref_ssim(r, d)
+    got, want = oracle.ms_ssim(r, d), oracle.ref_ms_ssim(r, d)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    assert oracle.psnr(r, r, bits) == (60.0 if bits == 8 else 72.0)

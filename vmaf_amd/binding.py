@@ -18,6 +18,7 @@ ATOM_NAMES = (["adm_num", "adm_den"] +
               [f"vif_{k}_scale{s}" for s in range(4) for k in ("num", "den")] +
               ["vif"])
 N_ATOMS = 20
+N_METRICS = 3          # psnr, ssim, ms_ssim (vmaf_hip_engine_get_metrics)
 
 
 class VmafHipError(RuntimeError):
@@ -57,6 +58,8 @@ def load_library():
                  "vmaf_hip_extract_host_raw_async"):
         getattr(L, name).argtypes = [vp, vp, vp, i, sz, sz, i, i, _dp]
     L.vmaf_hip_motion_seed_host_raw.argtypes = [vp, vp, i, sz]
+    L.vmaf_hip_engine_enable_metrics.argtypes = [vp, i, i, i, i]
+    L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_host_alloc.argtypes = [sz]
     L.vmaf_hip_host_alloc.restype = vp
@@ -93,6 +96,8 @@ class Engine:
             raise VmafHipError(_err(self.L))
         self._h = h
         self._keep = None
+        self._metrics_on = False
+        self.metrics = np.zeros((0, N_METRICS))      # of the frames of the last extract / extract_raw call
         if self.L.vmaf_hip_engine_set_conv_order(h, {"avx": 1, "scalar": 0}[order]):
             raise VmafHipError(_err(self.L))
 
@@ -109,6 +114,20 @@ class Engine:
     def __exit__(self, *a):
         self.close()
 
+    def enable_metrics(self, psnr=True, ssim=True, ms_ssim=True, ten_bit=False):
+        """Optional per-frame PSNR / SSIM / MS-SSIM (combo.c:168-230) next to the VMAF atoms; read them from
+        self.metrics [F,3] after extract() / extract_raw()."""
+        if self.L.vmaf_hip_engine_enable_metrics(self._h, int(psnr), int(ssim), int(ms_ssim), int(ten_bit)):
+            raise VmafHipError(_err(self.L))
+        self._metrics_on = bool(psnr or ssim or ms_ssim)
+
+    def _collect_metrics(self, rows, n):
+        if self._metrics_on:
+            m = np.zeros((n, N_METRICS))
+            if self.L.vmaf_hip_engine_get_metrics(self._h, m.ctypes.data_as(_dp), n):
+                raise VmafHipError(_err(self.L))
+            rows.append(m)
+
     # -- host arrays ------------------------------------------------------------------------
     def extract(self, ref, dis, continue_sequence=False):
         """ref, dis: float32 numpy [F,h,w] un-offset luma (8-bit units).  -> atoms [F,20]."""
@@ -120,13 +139,16 @@ class Engine:
         if (h, w) != (self.h, self.w) or dis.shape != ref.shape:
             raise VmafHipError(f"shape {ref.shape}/{dis.shape} does not match engine {self.h}x{self.w}")
         out = np.zeros((F, N_ATOMS))
+        rows = []
         done = 0
         while done < F:
             n = min(self.max_batch, F - done)
             if self.L.vmaf_hip_extract_host(self._h, ref[done:].ctypes.data, dis[done:].ctypes.data, w * 4, w * h * 4, n,
                                             1 if (continue_sequence or done) else 0, out[done:].ctypes.data_as(_dp)):
                 raise VmafHipError(_err(self.L))
+            self._collect_metrics(rows, n)
             done += n
+        self.metrics = np.concatenate(rows) if rows else np.zeros((0, N_METRICS))
         return out
 
     def extract_raw(self, ref, dis, continue_sequence=False):
@@ -142,13 +164,16 @@ class Engine:
             raise VmafHipError(f"shape {ref.shape}/{dis.shape} does not match engine {self.h}x{self.w}")
         bps = ref.dtype.itemsize
         out = np.zeros((F, N_ATOMS))
+        rows = []
         done = 0
         while done < F:
             n = min(self.max_batch, F - done)
             if self.L.vmaf_hip_extract_host_raw(self._h, ref[done:].ctypes.data, dis[done:].ctypes.data, bps, w * bps, w * h * bps, n,
                                                 1 if (continue_sequence or done) else 0, out[done:].ctypes.data_as(_dp)):
                 raise VmafHipError(_err(self.L))
+            self._collect_metrics(rows, n)
             done += n
+        self.metrics = np.concatenate(rows) if rows else np.zeros((0, N_METRICS))
         return out
 
     def extract_device_raw(self, d_ref, d_dis, nframes, bytes_per_sample, continue_sequence=False, out=None):

@@ -73,7 +73,10 @@ struct FrameSource {
     void *user = nullptr;
 };
 
-void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, std::vector<double> &atoms)
+struct MetricFlags { bool psnr = false, ssim = false, ms_ssim = false, ten_bit = false; bool any() const { return psnr || ssim || ms_ssim; } };
+
+void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, const MetricFlags &mf, std::vector<double> &atoms,
+                   std::vector<double> &metrics /* [frames][VMAF_HIP_METRICS] when mf.any() */)
 {
     if (w <= 0 || h <= 0) throw VmafException("wrong width " + std::to_string(w) + " or height " + std::to_string(h) + ".");
     const size_t stride = src.bps ? (size_t)w * src.bps : ((size_t)w * 4 + 31) / 32 * 32;   // ALIGN_CEIL, combo.c:106
@@ -92,6 +95,7 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, std:
         if (vmaf_hip_engine_create(&e, devices[g], w, h, batch)) throw VmafException(vmaf_hip_last_error());
         guard.engines.push_back(e);
         if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : 1)) throw VmafException(vmaf_hip_last_error());
+        if (mf.any() && vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit)) throw VmafException(vmaf_hip_last_error());
         for (int b = 0; b < 2; ++b) {
             float **pp[2] = { &slots[g].ref[b], &slots[g].dis[b] };
             for (auto p : pp) {
@@ -112,6 +116,11 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, std:
         if (vmaf_hip_engine_sync(guard.engines[g])) throw VmafException(vmaf_hip_last_error());
         if (atoms.size() < (s.pend_start + s.pend_n) * kAtoms) atoms.resize((s.pend_start + s.pend_n) * kAtoms);
         std::copy(s.out.begin(), s.out.begin() + (size_t)s.pend_n * kAtoms, atoms.begin() + s.pend_start * kAtoms);
+        if (mf.any()) {
+            if (metrics.size() < (s.pend_start + s.pend_n) * VMAF_HIP_METRICS) metrics.resize((s.pend_start + s.pend_n) * VMAF_HIP_METRICS);
+            if (vmaf_hip_engine_get_metrics(guard.engines[g], metrics.data() + s.pend_start * VMAF_HIP_METRICS, s.pend_n))
+                throw VmafException(vmaf_hip_last_error());
+        }
         s.pending = false;
     };
 
@@ -149,6 +158,7 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, std:
     }
     for (int i = 0; i < G; ++i) collect(i);
     atoms.resize(total * kAtoms);
+    if (mf.any()) metrics.resize(total * VMAF_HIP_METRICS);
 }
 
 const char *kKnownFeatures[] = { "adm2", "adm_scale0", "adm_scale1", "adm_scale2", "adm_scale3", "motion", "vif_scale0",
@@ -306,10 +316,7 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
                 const char *model_path, const char *log_path, const char *log_fmt, bool disable_clip, bool disable_avx,
                 bool enable_transform, bool do_psnr, bool do_ssim, bool do_ms_ssim, const char *pool_method)
 {
-    (void)fmt;
     std::printf("Start calculating VMAF score...\n");             // vmaf.cpp:638
-    if (do_psnr || do_ssim || do_ms_ssim)
-        throw VmafException("psnr/ssim/ms_ssim are not features of this build (MI355X VMAF v0.6.1 hot path only)");
     if (!model_path) throw VmafException("Error loading model (.pkl): null path");
     if (!(src.bps ? (void *)src.read_raw : (void *)src.read_frame)) throw VmafException("read_frame callback is null");
 
@@ -319,13 +326,26 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> atoms;
-    extract_atoms(src, width, height, disable_avx, atoms);
+    MetricFlags mf;
+    mf.psnr = do_psnr; mf.ssim = do_ssim; mf.ms_ssim = do_ms_ssim;
+    const size_t fl = fmt ? std::strlen(fmt) : 0;
+    mf.ten_bit = fl > 4 && std::strcmp(fmt + fl - 4, "10le") == 0;   // combo.c:171-186: the PSNR peak follows the format
+    std::vector<double> metrics;
+    extract_atoms(src, width, height, disable_avx, mf, atoms, metrics);
     const size_t F = atoms.size() / kAtoms;
     if (F == 0) throw VmafException("no frames delivered by read_frame");
     std::vector<double> vmaf;
     std::map<std::string, std::vector<double>> result;            // std::map: keys in alphabetical order, vmaf.h:126-134
     fuse(model, atoms, F, disable_clip, enable_transform, parse_devices()[0], vmaf, result);
     result["vmaf"] = vmaf;
+    const char *mnames[3] = { "psnr", "ssim", "ms_ssim" };            // vmaf.cpp:595-597
+    const bool mon[3] = { do_psnr, do_ssim, do_ms_ssim };
+    for (int k = 0; k < 3; ++k)
+        if (mon[k]) {
+            std::vector<double> &v = result[mnames[k]];
+            v.resize(F);
+            for (size_t i = 0; i < F; ++i) v[i] = metrics[i * VMAF_HIP_METRICS + k];
+        }
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     const double aggregate = pool(vmaf, pool_method);

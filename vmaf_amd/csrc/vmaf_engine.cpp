@@ -11,7 +11,9 @@
 // The VIF chain, the ADM chain and motion run on three streams and join before the reduction.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <vector>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +83,19 @@ struct vmaf_hip_engine {
     float rfac[8];
     int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
 
+    // optional metrics (combo.c:168-230): PSNR, SSIM, MS-SSIM on the un-offset planes
+    bool m_psnr = false, m_ssim = false, m_ms = false;
+    double psnr_peak = 255.0, psnr_max = 60.0;
+    hipStream_t s_iqa = nullptr;
+    hipEvent_t ev_iqa = nullptr;
+    int ssim_f = 1, ssim_w = 0, ssim_h = 0;        // ssim.c:86 decimation factor and the size _iqa_ssim sees
+    float *ssim_ref = nullptr, *ssim_dis = nullptr;
+    int ms_w[5] = {}, ms_h[5] = {};
+    float *ms_ref[5] = {}, *ms_dis[5] = {};        // [1..4]
+    size_t part_off_psnr = 0, part_off_ssim = 0, part_off_ms[5] = {};
+    int tiles_psnr = 0, tiles_ssim = 0, tiles_ms[5] = {};
+    std::vector<double> metrics;                   // [frames of the last synchronised call][VMAF_HIP_METRICS]
+
     // pending async call
     int pend_frames = 0;
     bool pend_first_has_motion = false;
@@ -124,6 +139,31 @@ void finish_atoms(const vmaf_hip_engine *e, const double *s, bool has_motion, do
     atoms[10] = has_motion ? (double)(float)((float)s[32] / (e->w * e->h)) : 0.0;
 }
 
+// psnr.c:51-55, ssim_tools.c:236-241, ms_ssim.c:268-312 from the reduced sums of one frame
+void finish_metrics(const vmaf_hip_engine *e, const double *s, double *m)
+{
+    m[0] = m[1] = m[2] = 0.0;
+    if (e->m_psnr) {
+        double noise = s[33];
+        noise /= (e->w * e->h);
+        const double eps = 1e-10;
+        m[0] = std::min(10 * std::log10(e->psnr_peak * e->psnr_peak / std::max(noise, eps)), e->psnr_max);
+    }
+    if (e->m_ssim) m[1] = (double)(float)(s[34] / (double)((e->ssim_w - 10) * (e->ssim_h - 10)));
+    if (e->m_ms) {
+        static const float alphas[5] = { 0.0000f, 0.0000f, 0.0000f, 0.0000f, 0.1333f };   // ms_ssim.c:62-64
+        static const float betas[5] = { 0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f };
+        static const float gammas[5] = { 0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f };
+        double msssim = 1.0;
+        for (int i = 0; i < 5; ++i) {
+            const double n = (double)((e->ms_w[i] - 10) * (e->ms_h[i] - 10));
+            const float l = (float)(s[38 + 4 * i + 1] / n), c = (float)(s[38 + 4 * i + 2] / n), st = (float)(s[38 + 4 * i + 3] / n);
+            msssim *= std::pow(l, alphas[i]) * std::pow(c, betas[i]) * std::pow(st, gammas[i]);
+        }
+        m[2] = msssim;
+    }
+}
+
 int alloc_planes(float **p, size_t floats) { HIP_TRY(hipMalloc((void **)p, floats * sizeof(float))); return 0; }
 
 int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
@@ -141,6 +181,37 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     HIP_TRY(hipEventRecord(e->ev_in, e->s_main));             // inputs (staging copies) are ready at this point
     HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
     HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
+
+    // ---- optional metrics on their own stream (combo.c:168-230: before the -128 offset, i.e. on the planes as given)
+    if (e->m_psnr || e->m_ssim || e->m_ms) {
+        hipStream_t q = e->s_iqa;
+        HIP_TRY(hipStreamWaitEvent(q, e->ev_in, 0));
+        if (e->m_psnr) HIP_TRY(vk_launch_psnr(d_ref, d_dis, fs, rs, e->w, e->h, nframes, e->partials + e->part_off_psnr, q));
+        if (e->m_ssim) {
+            const float *sr = d_ref, *sd = d_dis;
+            if (e->ssim_f > 1) {
+                HIP_TRY(vk_launch_box_decimate(d_ref, fs, rs, e->w, e->h, e->ssim_f, e->ssim_ref, e->ssim_w, e->ssim_h, nframes, q));
+                HIP_TRY(vk_launch_box_decimate(d_dis, fs, rs, e->w, e->h, e->ssim_f, e->ssim_dis, e->ssim_w, e->ssim_h, nframes, q));
+                sr = e->ssim_ref; sd = e->ssim_dis;
+            } else if (rs != e->w || fs != (size_t)e->w * e->h) {
+                return fail("ssim at decimation factor 1 needs dense input planes");
+            }
+            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, e->partials + e->part_off_ssim, q));
+        }
+        if (e->m_ms) {
+            if (rs != e->w || fs != (size_t)e->w * e->h) return fail("ms_ssim needs dense input planes");
+            const float *cr0 = d_ref, *cd0 = d_dis;
+            for (int i = 0; i < 5; ++i) {
+                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, e->partials + e->part_off_ms[i], q));
+                if (i < 4) {
+                    HIP_TRY(vk_launch_lpf_decimate(cr0, cd0, (size_t)e->ms_w[i] * e->ms_h[i], e->ms_w[i], e->ms_w[i], e->ms_h[i],
+                                                   e->ms_ref[i + 1], e->ms_dis[i + 1], e->ms_w[i + 1], e->ms_h[i + 1], nframes, q));
+                    cr0 = e->ms_ref[i + 1]; cd0 = e->ms_dis[i + 1];
+                }
+            }
+        }
+        HIP_TRY(hipEventRecord(e->ev_iqa, q));
+    }
 
     // ---- VIF chain (vif.c:130-275) on s_main
     const float *cr = d_ref, *cd = d_dis;
@@ -181,6 +252,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     // ---- join, reduce, copy back
     HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_adm, 0));
     HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_mot, 0));
+    if (e->m_psnr || e->m_ssim || e->m_ms) HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_iqa, 0));
     vk_reduce_table tab;
     int q = 0;
     for (int sc = 0; sc < 4; ++sc)
@@ -189,6 +261,10 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     for (int sc = 0; sc < 4; ++sc)
         for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c, 0, 0 };
     tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0, 0, 0 };
+    tab.d[q++] = { e->part_off_psnr, e->m_psnr ? e->tiles_psnr : 0, 1, 0, 0, 0 };
+    for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c, 0, 0 };
+    for (int i = 0; i < 5; ++i)
+        for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ms[i], e->m_ms ? e->tiles_ms[i] : 0, 4, c, 0, 0 };
     HIP_TRY(vk_launch_reduce(e->partials, &tab, nframes, e->sums_dev, e->s_main));
     HIP_TRY(hipMemcpyAsync(e->sums_host, e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
     if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1, e->s_main));
@@ -303,6 +379,10 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     (void)hipFree(e->carry[0]); (void)hipFree(e->carry[1]);
     (void)hipFree(e->stage_ref); (void)hipFree(e->stage_dis);
     (void)hipFree(e->raw_ref); (void)hipFree(e->raw_dis);
+    (void)hipFree(e->ssim_ref); (void)hipFree(e->ssim_dis);
+    for (int i = 1; i < 5; ++i) { (void)hipFree(e->ms_ref[i]); (void)hipFree(e->ms_dis[i]); }
+    if (e->ev_iqa) (void)hipEventDestroy(e->ev_iqa);
+    if (e->s_iqa && e->s_iqa != e->s_main) (void)hipStreamDestroy(e->s_iqa);
     (void)hipFree(e->partials); (void)hipFree(e->sums_dev);
     if (e->sums_host) (void)hipHostFree(e->sums_host);
     hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_t0, e->ev_t1, e->ev_k0, e->ev_k1 };
@@ -320,6 +400,73 @@ int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order)
     return 0;
 }
 
+int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit)
+{
+    if (!e) return fail("null engine");
+    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t B = (size_t)e->max_batch;
+    if (do_ssim) {
+        // ssim.c:86: scale = max(1, round(min(w, h) / 256)); iqa/decimate.c:40-41: sw = w / f + (w & 1)
+        const float a = (float)std::min(e->w, e->h) / 256.0f;
+        const int r = (a - (int)a >= 0.5) ? (int)a + (a > 0.0f ? 1 : -1) : (int)a;
+        e->ssim_f = std::max(1, r);
+        e->ssim_w = e->ssim_f > 1 ? e->w / e->ssim_f + (e->w & 1) : e->w;
+        e->ssim_h = e->ssim_f > 1 ? e->h / e->ssim_f + (e->h & 1) : e->h;
+        if (e->ssim_w < 11 || e->ssim_h < 11) return fail("frame too small for the 11x11 SSIM window after decimation by %d", e->ssim_f);
+    }
+    if (do_ms_ssim) {
+        int cw = e->w, ch = e->h;
+        for (int i = 0; i < 5; ++i) {                                  // ms_ssim.c:170-181
+            if (cw < 11 || ch < 11) return fail("ms_ssim: scale below 1x1 (frame %dx%d too small for 5 scales)", e->w, e->h);
+            cw /= 2; ch /= 2;
+        }
+        e->ms_w[0] = e->w; e->ms_h[0] = e->h;
+        for (int i = 1; i < 5; ++i) { e->ms_w[i] = e->ms_w[i - 1] / 2 + (e->ms_w[i - 1] & 1); e->ms_h[i] = e->ms_h[i - 1] / 2 + (e->ms_h[i - 1] & 1); }
+    }
+    if (!e->s_iqa) {
+        if (e->serial) e->s_iqa = e->s_main;
+        else HIP_TRY(hipStreamCreateWithFlags(&e->s_iqa, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_iqa, hipEventDisableTiming));
+    }
+    if (do_ssim && e->ssim_f > 1 && !e->ssim_ref) {
+        if (alloc_planes(&e->ssim_ref, B * e->ssim_w * e->ssim_h) || alloc_planes(&e->ssim_dis, B * e->ssim_w * e->ssim_h)) return 1;
+    }
+    if (do_ms_ssim && !e->ms_ref[1]) {
+        for (int i = 1; i < 5; ++i)
+            if (alloc_planes(&e->ms_ref[i], B * e->ms_w[i] * e->ms_h[i]) || alloc_planes(&e->ms_dis[i], B * e->ms_w[i] * e->ms_h[i])) return 1;
+    }
+    // the partial-sum buffer grows by the metric sections
+    size_t off = e->part_total;
+    if (!e->tiles_psnr) {
+        e->tiles_psnr = vk_psnr_tiles(e->h); e->part_off_psnr = off; off += B * e->tiles_psnr;
+    }
+    if (do_ssim && !e->tiles_ssim) { e->tiles_ssim = vk_ssim_tiles(e->ssim_w, e->ssim_h); e->part_off_ssim = off; off += B * e->tiles_ssim * 4; }
+    if (do_ms_ssim && !e->tiles_ms[0])
+        for (int i = 0; i < 5; ++i) { e->tiles_ms[i] = vk_ssim_tiles(e->ms_w[i], e->ms_h[i]); e->part_off_ms[i] = off; off += B * e->tiles_ms[i] * 4; }
+    if (off != e->part_total) {
+        HIP_TRY(hipStreamSynchronize(e->s_main));
+        (void)hipFree(e->partials);
+        e->partials = nullptr;
+        HIP_TRY(hipMalloc((void **)&e->partials, off * sizeof(double)));
+        e->part_total = off;
+    }
+    e->m_psnr = do_psnr != 0; e->m_ssim = do_ssim != 0; e->m_ms = do_ms_ssim != 0;
+    e->psnr_peak = ten_bit ? 255.75 : 255.0;                           // combo.c:171-186
+    e->psnr_max = ten_bit ? 72.0 : 60.0;
+    return 0;
+}
+
+int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes)
+{
+    if (!e || !out) return fail("null argument");
+    if (!(e->m_psnr || e->m_ssim || e->m_ms)) return fail("no metric enabled on this engine");
+    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (nframes < 0 || (size_t)nframes * VMAF_HIP_METRICS > e->metrics.size()) return fail("the last call scored %zu frames, %d asked for", e->metrics.size() / VMAF_HIP_METRICS, nframes);
+    std::copy(e->metrics.begin(), e->metrics.begin() + (size_t)nframes * VMAF_HIP_METRICS, out);
+    return 0;
+}
+
 int vmaf_hip_engine_sync(vmaf_hip_engine *e)
 {
     if (!e) return fail("null engine");
@@ -328,6 +475,11 @@ int vmaf_hip_engine_sync(vmaf_hip_engine *e)
     for (int f = 0; f < e->pend_frames; ++f)
         finish_atoms(e, e->sums_host + (size_t)f * VK_NSUMS, f > 0 || e->pend_first_has_motion,
                      e->pend_out + (size_t)f * VMAF_HIP_ATOMS);
+    if (e->pend_frames && (e->m_psnr || e->m_ssim || e->m_ms)) {
+        e->metrics.resize((size_t)e->pend_frames * VMAF_HIP_METRICS);
+        for (int f = 0; f < e->pend_frames; ++f)
+            finish_metrics(e, e->sums_host + (size_t)f * VK_NSUMS, e->metrics.data() + (size_t)f * VMAF_HIP_METRICS);
+    }
     e->pend_frames = 0;
     return 0;
 }

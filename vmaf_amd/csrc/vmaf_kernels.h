@@ -9,7 +9,11 @@
 //   [0..7]   VIF  num,den of scale 0..3
 //   [8..31]  ADM  scale s: num_h,num_v,num_d,den_h,den_v,den_d  (cube sums over the centre window)
 //   [32]     motion: sum |blur_prev - blur_cur|
-#define VK_NSUMS 33
+// optional metrics (zero sections when not enabled):
+//   [33]     PSNR: sum (ref - dis)^2
+//   [34..37] SSIM: sum l*c*s, sum l, sum c, sum s over the valid window of the decimated planes
+//   [38..57] MS-SSIM scale 0..4: the same four sums each
+#define VK_NSUMS 58
 
 typedef struct {
     size_t offset;   // first double of this section in the partial buffer
@@ -44,6 +48,16 @@ hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, in
 // raw luma (1 or 2 bytes per sample, 2 = little-endian words / 4.0) -> dense fp32 planes [nframes][h][w]
 hipError_t vk_launch_widen(const void *src, int bytes_per_sample, size_t src_row_bytes, size_t src_frame_bytes, float *dst,
                            int w, int h, int nframes, hipStream_t s);
+// optional metrics (psnr.c, ssim.c, ms_ssim.c, iqa/): all on un-offset planes
+int vk_psnr_tiles(int h);
+int vk_ssim_tiles(int w, int h);    // w, h = size of the planes _iqa_ssim sees
+hipError_t vk_launch_psnr(const float *ref, const float *dis, size_t frame_stride, int row_stride, int w, int h, int nframes,
+                          double *partial, hipStream_t s);
+hipError_t vk_launch_box_decimate(const float *src, size_t src_frame_stride, int src_row_stride, int w, int h, int f, float *dst,
+                                  int sw, int sh, int nframes, hipStream_t s);
+hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h,
+                                  float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s);
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, double *partial, hipStream_t s);
 hipError_t vk_launch_reduce(const double *partial, const vk_reduce_table *tab, int nframes, double *sums, hipStream_t s);
 hipError_t vk_launch_svm(const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho, const double *x,
                          int n, double *out, hipStream_t s);

@@ -854,6 +854,162 @@ __global__ __launch_bounds__(256) void widen_kernel(const unsigned char *__restr
     }
 }
 
+// ---------------------------------------------------------------- optional metrics: PSNR, SSIM, MS-SSIM
+// combo.c:168-230 -> psnr.c, ssim.c, ms_ssim.c, iqa/*.  They work on the UN-OFFSET planes.  The reference keeps
+// float products and double running sums (iqa/convolve.c with IQA_CONVOLVE_1D: horizontal pass, float store,
+// vertical pass, float store); the kernels keep the same types expression by expression.
+constexpr int PSNR_ROWS = 8;
+
+// psnr.c:37-50: sum of (float)(diff * diff) in double; one workgroup per PSNR_ROWS rows
+__global__ __launch_bounds__(256) void psnr_kernel(const float *__restrict__ ref, const float *__restrict__ dis, size_t frame_stride,
+                                                   int row_stride, int w, int h, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    const float *fr = ref + (size_t)blockIdx.z * frame_stride, *fd = dis + (size_t)blockIdx.z * frame_stride;
+    double acc[1] = { 0.0 };
+    const int y1 = min(h, (int)(blockIdx.x + 1) * PSNR_ROWS);
+    for (int y = blockIdx.x * PSNR_ROWS; y < y1; ++y)
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const float diff = fr[(size_t)y * row_stride + x] - fd[(size_t)y * row_stride + x];
+            acc[0] += (double)(diff * diff);
+        }
+    block_reduce_store<1, 4>(acc, red, partial + (size_t)blockIdx.z * gridDim.x + blockIdx.x);
+}
+
+// KBND_SYMMETRIC, iqa/convolve.c:35-42 (clamped for workgroups hanging over the plane)
+__device__ __forceinline__ int sym_idx(int i, int n)
+{
+    i = i < 0 ? -1 - i : i;
+    i = i >= n ? 2 * n - i - 1 : i;
+    return min(max(i, 0), n - 1);
+}
+
+// ssim.c:117-163: _iqa_decimate by `f` with the f x f box kernel of 1.0f/(f*f) (2-D form, iqa/convolve.c:219-268,
+// iqa/decimate.c:37-59): out (x, y) = kernel centred (even f: one tap more to the left/top) on (x*f, y*f).
+__global__ __launch_bounds__(256) void box_decimate_kernel(const float *__restrict__ src, size_t src_frame_stride, int src_row_stride,
+                                                           int w, int h, int f, float *__restrict__ dst, int sw, int sh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= sw || y >= sh) return;
+    const float *img = src + (size_t)blockIdx.z * src_frame_stride;
+    const int uc = f / 2, even = (f & 1) ? 0 : 1;
+    const float kv = 1.0f / (f * f);
+    double sum = 0.0;
+    for (int v = -uc; v <= uc - even; ++v) {
+        const float *row = img + (size_t)sym_idx(y * f + v, h) * src_row_stride;
+        for (int u = -uc; u <= uc - even; ++u) sum += (double)(row[sym_idx(x * f + u, w)] * kv);
+    }
+    dst[((size_t)blockIdx.z * sh + y) * sw + x] = (float)sum;
+}
+
+// ms_ssim.c:41-51: 9/7 biorthogonal low-pass, the 2-D table _iqa_decimate applies (81 taps, row-major)
+constexpr float kLpf9[81] = {
+     0.000714f,-0.000450f,-0.002090f, 0.007132f, 0.016114f, 0.007132f,-0.002090f,-0.000450f, 0.000714f,
+    -0.000450f, 0.000283f, 0.001316f,-0.004490f,-0.010146f,-0.004490f, 0.001316f, 0.000283f,-0.000450f,
+    -0.002090f, 0.001316f, 0.006115f,-0.020867f,-0.047149f,-0.020867f, 0.006115f, 0.001316f,-0.002090f,
+     0.007132f,-0.004490f,-0.020867f, 0.071207f, 0.160885f, 0.071207f,-0.020867f,-0.004490f, 0.007132f,
+     0.016114f,-0.010146f,-0.047149f, 0.160885f, 0.363505f, 0.160885f,-0.047149f,-0.010146f, 0.016114f,
+     0.007132f,-0.004490f,-0.020867f, 0.071207f, 0.160885f, 0.071207f,-0.020867f,-0.004490f, 0.007132f,
+    -0.002090f, 0.001316f, 0.006115f,-0.020867f,-0.047149f,-0.020867f, 0.006115f, 0.001316f,-0.002090f,
+    -0.000450f, 0.000283f, 0.001316f,-0.004490f,-0.010146f,-0.004490f, 0.001316f, 0.000283f,-0.000450f,
+     0.000714f,-0.000450f,-0.002090f, 0.007132f, 0.016114f, 0.007132f,-0.002090f,-0.000450f, 0.000714f,
+};
+constexpr int LPF_TW = 32, LPF_TH = 8, LPF_IW = 2 * LPF_TW + 8, LPF_IH = 2 * LPF_TH + 7;   // staged 72 x 23
+
+// ms_ssim.c:250-266: one level of the pyramid, both planes of a frame pair handled by blockIdx.z = 2*frame + plane
+__global__ __launch_bounds__(256) void lpf_decimate_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                           size_t src_frame_stride, int src_row_stride, int w, int h,
+                                                           float *__restrict__ oref, float *__restrict__ odis, int sw, int sh)
+{
+    __shared__ float tile[LPF_IH * LPF_IW];
+    const int frame = blockIdx.z >> 1, plane = blockIdx.z & 1;
+    const float *img = (plane ? dis : ref) + (size_t)frame * src_frame_stride;
+    float *out = (plane ? odis : oref) + (size_t)frame * sw * sh;
+    const int x0 = blockIdx.x * LPF_TW, y0 = blockIdx.y * LPF_TH;
+    for (int idx = threadIdx.x; idx < LPF_IH * LPF_IW; idx += 256) {
+        const int ly = idx / LPF_IW, lx = idx - ly * LPF_IW;
+        tile[idx] = img[(size_t)sym_idx(2 * y0 - 4 + ly, h) * src_row_stride + sym_idx(2 * x0 - 4 + lx, w)];
+    }
+    __syncthreads();
+    const int ox = threadIdx.x & 31, oy = threadIdx.x >> 5;
+    double sum = 0.0;
+#pragma unroll
+    for (int v = 0; v < 9; ++v)
+#pragma unroll
+        for (int u = 0; u < 9; ++u) sum += (double)(tile[(2 * oy + v) * LPF_IW + 2 * ox + u] * kLpf9[v * 9 + u]);
+    if (x0 + ox < sw && y0 + oy < sh) out[(size_t)(y0 + oy) * sw + x0 + ox] = (float)sum;
+}
+
+// ssim_tools.h: g_gaussian_window_h == g_gaussian_window_v
+constexpr float kSsimWin[11] = { 0.001028f, 0.007599f, 0.036001f, 0.109361f, 0.213006f, 0.266012f, 0.213006f, 0.109361f,
+                                 0.036001f, 0.007599f, 0.001028f };
+constexpr int SS_TW = 32, SS_TH = 16, SS_IW = SS_TW + 10, SS_IH = SS_TH + 10, SS_IP = SS_IW + 1;
+
+// _iqa_ssim with default arguments (iqa/ssim_tools.c:92-243) on dense planes [frame][h][w]: "valid" 11-tap
+// separable Gaussian of {ref, cmp, ref^2, cmp^2, ref*cmp} (horizontal pass first, iqa/convolve.c:113-143), sigma,
+// l / c / s per pixel in double, four sums per workgroup: sum(l*c*s), sum(l), sum(c), sum(s).
+__global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
+                                                        double *__restrict__ partial)
+{
+    __shared__ float pl[5][SS_IH * SS_IP];
+    __shared__ float hc[5][SS_IH * SS_TW];
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    const int vw = w - 10, vh = h - 10;                              // valid output size
+    const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
+    const float *fr = ref + (size_t)blockIdx.z * w * h, *fc = cmp + (size_t)blockIdx.z * w * h;
+    for (int idx = tid; idx < SS_IH * SS_IW; idx += 256) {
+        const int ly = idx / SS_IW, lx = idx - ly * SS_IW;
+        const size_t g = (size_t)min(y0 + ly, h - 1) * w + min(x0 + lx, w - 1);   // clamped reads feed masked outputs only
+        const float a = fr[g], b = fc[g];
+        const int o = ly * SS_IP + lx;
+        pl[0][o] = a; pl[1][o] = b; pl[2][o] = a * a; pl[3][o] = b * b; pl[4][o] = a * b;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 5 * SS_IH * SS_TW; idx += 256) {
+        const int q = idx / (SS_IH * SS_TW), rem = idx - q * (SS_IH * SS_TW);
+        const int ly = rem / SS_TW, lx = rem - ly * SS_TW;
+        const float *p = &pl[q][ly * SS_IP + lx];
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) sum += (double)(p[k] * kSsimWin[k]);
+        hc[q][rem] = (float)sum;
+    }
+    __syncthreads();
+    const float K1 = 0.01f, K2 = 0.03f;
+    const int L = 255;
+    const float C1 = (K1 * L) * (K1 * L), C2 = (K2 * L) * (K2 * L);
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int it = 0; it < SS_TH * SS_TW / 256; ++it) {
+        const int ox = tid & 31, oy = (tid >> 5) + it * 8;
+        float m[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) sum += (double)(hc[q][(oy + k) * SS_TW + ox] * kSsimWin[k]);
+            m[q] = (float)sum;
+        }
+        if (x0 + ox < vw && y0 + oy < vh) {
+            const float ref_mu = m[0], cmp_mu = m[1];
+            float rss = m[2], css = m[3], sb = m[4];
+            rss -= ref_mu * ref_mu;
+            css -= cmp_mu * cmp_mu;
+            rss = (float)((0.0 > rss) ? 0.0 : rss);
+            css = (float)((0.0 > css) ? 0.0 : css);
+            sb -= ref_mu * cmp_mu;
+            const double srsc = sqrt((double)(rss * css));
+            const double l = (2.0 * ref_mu * cmp_mu + C1) / (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
+            const double c = (2.0 * srsc + C2) / (double)(rss + css + C2);
+            const double s = (sb + C2 / 2.0) / (srsc + C2 / 2.0);
+            acc[0] += l * c * s;
+            acc[1] += l; acc[2] += c; acc[3] += s;
+        }
+    }
+    block_reduce_store<4, 4>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x) * 4);
+}
+
 // ---------------------------------------------------------------- final reduction
 __global__ __launch_bounds__(256) void reduce_kernel(const double *__restrict__ partial, vk_reduce_table tab,
                                                      double *__restrict__ sums /* [frame][VK_NSUMS] */)
@@ -980,6 +1136,39 @@ hipError_t vk_launch_widen(const void *src, int bytes_per_sample, size_t src_row
         widen_kernel<unsigned char><<<g, 256, 0, s>>>((const unsigned char *)src, src_row_bytes, src_frame_bytes, dst, w, h, vec_ok);
     else
         widen_kernel<unsigned short><<<g, 256, 0, s>>>((const unsigned char *)src, src_row_bytes, src_frame_bytes, dst, w, h, vec_ok);
+    return hipGetLastError();
+}
+
+int vk_psnr_tiles(int h) { return (h + PSNR_ROWS - 1) / PSNR_ROWS; }
+int vk_ssim_tiles(int w, int h) { return w < 11 || h < 11 ? 0 : ((w - 10 + SS_TW - 1) / SS_TW) * ((h - 10 + SS_TH - 1) / SS_TH); }
+
+hipError_t vk_launch_psnr(const float *ref, const float *dis, size_t frame_stride, int row_stride, int w, int h, int nframes,
+                          double *partial, hipStream_t s)
+{
+    psnr_kernel<<<dim3(vk_psnr_tiles(h), 1, nframes), 256, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial);
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_box_decimate(const float *src, size_t src_frame_stride, int src_row_stride, int w, int h, int f, float *dst,
+                                  int sw, int sh, int nframes, hipStream_t s)
+{
+    box_decimate_kernel<<<dim3((sw + 63) / 64, (sh + 3) / 4, nframes), 256, 0, s>>>(src, src_frame_stride, src_row_stride, w, h, f, dst, sw, sh);
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h,
+                                  float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s)
+{
+    lpf_decimate_kernel<<<dim3((sw + LPF_TW - 1) / LPF_TW, (sh + LPF_TH - 1) / LPF_TH, 2 * nframes), 256, 0, s>>>(
+        ref, dis, src_frame_stride, src_row_stride, w, h, oref, odis, sw, sh);
+    return hipGetLastError();
+}
+
+// ref, cmp: dense planes [nframes][h][w]; partial receives vk_ssim_tiles(w, h) * 4 doubles per frame
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, double *partial, hipStream_t s)
+{
+    const dim3 g((w - 10 + SS_TW - 1) / SS_TW, (h - 10 + SS_TH - 1) / SS_TH, nframes);
+    ssim_stat_kernel<<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
     return hipGetLastError();
 }
 
