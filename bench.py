@@ -95,13 +95,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a box with ONE GPU - every rank uses cuda:0 and the
+    # gather goes over gloo with host tensors.  Never a measurement; the driver's runs use RCCL, one rank per GPU.
+    rehearsal = world > 1 and os.environ.get("BENCH_REHEARSAL", "0") not in ("", "0")
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if rehearsal else dev
     B, K = FRAMES_PER_STEP, args.steps
 
     # ---- synthetic clip, resident in HBM as fp32 luma
@@ -117,6 +126,11 @@ def main():
     scratch = np.zeros((B, 20))
     for i in range(args.warmup):
         eng.extract_device(t_ref, t_dis, B, continue_sequence=i > 0, out=scratch)
+    # untimed warm-up of everything the timed region touches for the first time otherwise: the RCCL communicator
+    # (lazy initialisation at the first collective costs seconds) and the fusion call's one-off allocations
+    warm = sharding.gather_rows(scratch, dist if world > 1 else None, coll_dev)
+    if rank == 0:
+        vmaf_amd.predict_from_atoms(warm, MODEL, device=local_rank)
     eng.arm_timing()
 
     def barrier():
@@ -134,13 +148,13 @@ def main():
         ms = eng.last_kernel_ms(1)
         if ms > 0:
             k_ms.append(ms)
-    flat = sharding.gather_rows(atoms.reshape(K * B, 20), dist if world > 1 else None, dev)   # one RCCL gather, rank order = frame order
+    flat = sharding.gather_rows(atoms.reshape(K * B, 20), dist if world > 1 else None, coll_dev)   # one RCCL gather, rank order = frame order
     if rank == 0:
         vmaf, _ = vmaf_amd.predict_from_atoms(flat, MODEL, device=local_rank)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
