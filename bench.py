@@ -38,6 +38,9 @@ from vmaf_amd import sharding, synth  # noqa: E402
 
 W, H = 1920, 1080
 FRAMES_PER_STEP = 30
+BITS = 8
+# name -> (width, height, bits, frames per step): BASELINE.json configs[1], [2] (per-GPU share) and [3] (one pair)
+WORKLOADS = {"1080p": (1920, 1080, 8, 30), "4k10": (3840, 2160, 10, 8), "720p": (1280, 720, 8, 48)}
 MODEL = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PATH_BYTES_PER_PX = 26.5        # algorithmic bytes of the whole path per luma pixel
@@ -79,7 +82,7 @@ def cpu_baseline(ref, dis, budget_s=20.0, max_frames=64):
         n += 1
     dt = time.perf_counter() - t0
     fps = n / dt
-    sample = f"{n} frames (adm + motion + vif per frame) of the same 1080p clip in {dt:.1f}s"
+    sample = f"{n} frames (adm + motion + vif per frame) of the same {W}x{H} clip in {dt:.1f}s"
     return {"value": round(fps, 3), "unit": "frames/sec", "cores": 1, "kind": kind, "sample": sample}
 
 
@@ -89,9 +92,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
+                    help="1080p = BASELINE.json configs[1], the headline workload (default); the others are for DESIGN.md's table")
     ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
     args = ap.parse_args()
 
+    global W, H, BITS, FRAMES_PER_STEP
+    W, H, BITS, FRAMES_PER_STEP = WORKLOADS[args.workload]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,8 +121,8 @@ def main():
     B, K = FRAMES_PER_STEP, args.steps
 
     # ---- synthetic clip, resident in HBM as fp32 luma
-    r8, d8 = synth.make_clip(W, H, B, seed=1234)
-    ref, dis = synth.to_luma_f32(r8), synth.to_luma_f32(d8)
+    r8, d8 = synth.make_clip(W, H, B, bits=BITS, seed=1234)
+    ref, dis = synth.to_luma_f32(r8, BITS), synth.to_luma_f32(d8, BITS)
     t_ref, t_dis = torch.from_numpy(ref).to(dev), torch.from_numpy(dis).to(dev)
     torch.cuda.synchronize()
 
@@ -177,10 +184,10 @@ def main():
                 roof["valu_issue"] = {"wave_insts_per_launch": prof["valu"], "achieved": round(rate / 1e12, 3),
                                       "peak": round(VALU_PEAK_WINST / 1e12, 3), "unit": "T wave-inst/s",
                                       "frac": round(rate / VALU_PEAK_WINST, 3)}
-        line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",
+        line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1" if args.workload == "1080p" else f"frames/sec (whole node) {args.workload} VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",
                 "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "synthetic 1920x1080 yuv420p 8-bit ref/dis pair, vmaf_v0.6.1, fp32 luma resident in HBM" +
+                "config": {"workload": f"synthetic {W}x{H} yuv420p {BITS}-bit ref/dis pair, vmaf_v0.6.1, fp32 luma resident in HBM" +
                                        (" + psnr/ssim/ms_ssim" if args.metrics else ""),
                            "frames_per_step_per_gpu": B, "frames_total": frames,
                            "parallelism": f"frame-range x{world}, 1-frame motion halo" if world > 1 else "single GPU"},

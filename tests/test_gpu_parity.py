@@ -256,3 +256,22 @@ def test_metrics_identical_frames_and_too_small_frames():
         with pytest.raises(vmaf_amd.VmafHipError, match="scale below 1x1"):
             e.enable_metrics()
         e.enable_metrics(ms_ssim=False)
+
+
+def test_4k_10bit_properties_and_oracle_spot_check():
+    """BASELINE.json configs[2] at full size (3840x2160 yuv420p10le): one frame against the oracle, and the
+    size-independent properties on a short clip - batch-size independence, shard = whole (motion halo), raw 16-bit
+    ingest = fp32 ingest - all bit for bit."""
+    w, h = 3840, 2160
+    r, d = synth.make_clip(w, h, 3, bits=10, seed=77, cuts=(2,))
+    ref, dis = synth.to_luma_f32(r, 10), synth.to_luma_f32(d, 10)
+    with vmaf_amd.Engine(w, h, max_batch=3) as e:
+        whole = e.extract(ref, dis)
+    with vmaf_amd.Engine(w, h, max_batch=1) as e:
+        assert np.array_equal(e.extract(ref, dis), whole)
+        assert np.array_equal(e.extract_raw(r, d), whole)
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:
+        e.motion_seed(ref[1])
+        assert np.array_equal(e.extract(ref[2:], dis[2:], continue_sequence=True), whole[2:])
+    want = oracle.clip_atoms(ref[:2], dis[:2], oracle.ORDER_AVX)
+    _check(whole[:2], want, "4K 10-bit")
