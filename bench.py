@@ -150,11 +150,17 @@ def main():
     t0 = time.perf_counter()
     if rank > 0:
         eng.motion_seed(t_ref[B - 1])                  # halo: the frame before this rank's range
-    for k in range(K):
-        eng.extract_device(t_ref, t_dis, B, continue_sequence=(k > 0 or rank > 0), out=atoms[k])
-        ms = eng.last_kernel_ms(1)
-        if ms > 0:
-            k_ms.append(ms)
+    for k in range(K):                                  # two batches in flight: batch k is enqueued before batch k-1 is collected
+        eng.extract_device(t_ref, t_dis, B, continue_sequence=(k > 0 or rank > 0), out=atoms[k], sync=False)
+        if k > 0:
+            eng.sync_oldest()
+            ms = eng.last_kernel_ms(1)
+            if ms > 0:
+                k_ms.append(ms)
+    eng.sync()
+    ms = eng.last_kernel_ms(1)
+    if ms > 0:
+        k_ms.append(ms)
     flat = sharding.gather_rows(atoms.reshape(K * B, 20), dist if world > 1 else None, coll_dev)   # one RCCL gather, rank order = frame order
     if rank == 0:
         vmaf, _ = vmaf_amd.predict_from_atoms(flat, MODEL, device=local_rank)

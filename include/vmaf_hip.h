@@ -88,6 +88,13 @@ int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const fl
                                 size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
                                 int continue_sequence, double *atoms_out);
 int vmaf_hip_engine_sync(vmaf_hip_engine *e);
+/*
+ * Up to TWO asynchronous extract calls may be in flight on one engine, so that the host can enqueue batch k+1 while
+ * batch k is still running and the GPU never idles between batches.  vmaf_hip_engine_sync() finishes all of them in
+ * order; vmaf_hip_engine_sync_oldest() waits for the oldest only (its atoms_out is complete on return).  A third
+ * async call, a motion seed or vmaf_hip_engine_enable_metrics with calls in flight is an error.
+ */
+int vmaf_hip_engine_sync_oldest(vmaf_hip_engine *e);
 
 /*
  * Raw-luma forms of the four extract calls: the planes hold the samples as the YUV file does -

@@ -275,3 +275,29 @@ def test_4k_10bit_properties_and_oracle_spot_check():
         assert np.array_equal(e.extract(ref[2:], dis[2:], continue_sequence=True), whole[2:])
     want = oracle.clip_atoms(ref[:2], dis[:2], oracle.ORDER_AVX)
     _check(whole[:2], want, "4K 10-bit")
+
+
+def test_two_async_calls_in_flight():
+    """include/vmaf_hip.h: batch k+1 may be enqueued while batch k runs; results equal the synchronous run, a third
+    call in flight is refused, sync_oldest with nothing in flight is an error."""
+    torch = pytest.importorskip("torch")
+    ref, dis = _clip(256, 144, 6, seed=13, cuts=(3,))
+    with vmaf_amd.Engine(256, 144, max_batch=2) as e:
+        want = e.extract(ref, dis)
+    tr, td = torch.from_numpy(ref).cuda(), torch.from_numpy(dis).cuda()
+    torch.cuda.synchronize()
+    got = np.zeros((3, 2, 20))
+    with vmaf_amd.Engine(256, 144, max_batch=2) as e:
+        with pytest.raises(vmaf_amd.VmafHipError, match="no async extract"):
+            e.sync_oldest()
+        e.extract_device(tr[0:2], td[0:2], 2, out=got[0], sync=False)
+        e.extract_device(tr[2:4], td[2:4], 2, continue_sequence=True, out=got[1], sync=False)
+        with pytest.raises(vmaf_amd.VmafHipError, match="in flight"):
+            e.extract_device(tr[4:6], td[4:6], 2, continue_sequence=True, out=got[2], sync=False)
+        with pytest.raises(vmaf_amd.VmafHipError, match="not been synchronised"):
+            e.motion_seed(tr[0])
+        e.sync_oldest()
+        assert np.array_equal(got[0], want[0:2])
+        e.extract_device(tr[4:6], td[4:6], 2, continue_sequence=True, out=got[2], sync=False)
+        e.sync()
+        assert np.array_equal(got.reshape(6, 20), want)

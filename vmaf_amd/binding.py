@@ -61,6 +61,7 @@ def load_library():
     L.vmaf_hip_engine_enable_metrics.argtypes = [vp, i, i, i, i]
     L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
     L.vmaf_hip_engine_sync.argtypes = [vp]
+    L.vmaf_hip_engine_sync_oldest.argtypes = [vp]
     L.vmaf_hip_host_alloc.argtypes = [sz]
     L.vmaf_hip_host_alloc.restype = vp
     L.vmaf_hip_host_free.argtypes = [vp]
@@ -201,11 +202,16 @@ class Engine:
         fn = self.L.vmaf_hip_extract_device if sync else self.L.vmaf_hip_extract_device_async
         if fn(self._h, pr, pd, rs, fs, nframes, 1 if continue_sequence else 0, out.ctypes.data_as(_dp)):
             raise VmafHipError(_err(self.L))
-        self._keep = (d_ref, d_dis, out)
+        self._keep = ([self._keep[-1]] if self._keep else []) + [(d_ref, d_dis, out)]   # buffers of the calls in flight
         return out
 
     def sync(self):
         if self.L.vmaf_hip_engine_sync(self._h):
+            raise VmafHipError(_err(self.L))
+
+    def sync_oldest(self):
+        """Finish the oldest of the (at most two) asynchronous extract calls in flight."""
+        if self.L.vmaf_hip_engine_sync_oldest(self._h):
             raise VmafHipError(_err(self.L))
 
     def motion_seed(self, ref_frame):

@@ -59,11 +59,13 @@ float adm_rfactor(int lambda, int theta)
 
 }  // namespace
 
+constexpr int kDepth = 2;
+
 struct vmaf_hip_engine {
     int device = 0, w = 0, h = 0, max_batch = 0;
     hipStream_t s_main = nullptr, s_adm = nullptr, s_mot = nullptr;
     hipEvent_t ev_in = nullptr, ev_adm = nullptr, ev_mot = nullptr;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    hipEvent_t ev_t0[kDepth] = {}, ev_t1[kDepth] = {}, ev_k0[kDepth] = {}, ev_k1[kDepth] = {}, ev_done[kDepth] = {};
     bool timed = false;
     bool serial = false;
     int order = 1;                 // convolution tap order: 1 = reference AVX path (default), 0 = scalar path
@@ -77,7 +79,7 @@ struct vmaf_hip_engine {
     int carry_cur = 0;
     bool carry_valid = false;
     float *stage_ref = nullptr, *stage_dis = nullptr;
-    double *partials = nullptr, *sums_dev = nullptr, *sums_host = nullptr;
+    double *partials = nullptr, *sums_dev = nullptr, *sums_host[kDepth] = {};
     size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
     int tiles_vif[4], tiles_adm[4], tiles_mot;
     float rfac[8];
@@ -96,10 +98,10 @@ struct vmaf_hip_engine {
     int tiles_psnr = 0, tiles_ssim = 0, tiles_ms[5] = {};
     std::vector<double> metrics;                   // [frames of the last synchronised call][VMAF_HIP_METRICS]
 
-    // pending async call
-    int pend_frames = 0;
-    bool pend_first_has_motion = false;
-    double *pend_out = nullptr;
+    // asynchronous calls in flight (at most kDepth: the host can enqueue batch k+1 while batch k runs, so the GPU
+    // does not idle between batches); slot i owns sums_host[i] and the events [i]
+    struct Pending { int frames = 0; bool first_has_motion = false; double *out = nullptr; } pend[kDepth];
+    int pend_head = 0, pend_count = 0, last_slot = 0;
 };
 
 namespace {
@@ -177,7 +179,8 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     const bool has_carry = continue_sequence && e->carry_valid;
     if (continue_sequence && !e->carry_valid) return fail("continue_sequence set but the engine holds no previous frame");
 
-    if (e->timed) HIP_TRY(hipEventRecord(e->ev_t0, e->s_main));
+    const int slot = (e->pend_head + e->pend_count) % kDepth;
+    if (e->timed) HIP_TRY(hipEventRecord(e->ev_t0[slot], e->s_main));
     HIP_TRY(hipEventRecord(e->ev_in, e->s_main));             // inputs (staging copies) are ready at this point
     HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
     HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
@@ -222,10 +225,10 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
         float *nr = sc < 3 ? e->vif_ref[sc + 1] : nullptr, *nd = sc < 3 ? e->vif_dis[sc + 1] : nullptr;
         const size_t nfs = sc < 3 ? (size_t)e->vw[sc + 1] * e->vh[sc + 1] : 0;
         const int nrs = sc < 3 ? e->vw[sc + 1] : 0;
-        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0, e->s_main));
+        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0[slot], e->s_main));
         HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc],
                                    nr, nd, nfs, nrs, e->s_main));
-        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1, e->s_main));
+        if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1[slot], e->s_main));
         cr = nr; cd = nd; cfs = nfs; crs = nrs;
     }
 
@@ -266,8 +269,9 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     for (int i = 0; i < 5; ++i)
         for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ms[i], e->m_ms ? e->tiles_ms[i] : 0, 4, c, 0, 0 };
     HIP_TRY(vk_launch_reduce(e->partials, &tab, nframes, e->sums_dev, e->s_main));
-    HIP_TRY(hipMemcpyAsync(e->sums_host, e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
-    if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1, e->s_main));
+    HIP_TRY(hipMemcpyAsync(e->sums_host[slot], e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
+    if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1[slot], e->s_main));
+    HIP_TRY(hipEventRecord(e->ev_done[slot], e->s_main));
     return 0;
 }
 
@@ -276,8 +280,37 @@ int check_call(vmaf_hip_engine *e, const void *a, const void *b, int nframes, co
     if (!e) return fail("null engine");
     if (!a || !b || !out) return fail("null pointer argument");
     if (nframes <= 0 || nframes > e->max_batch) return fail("nframes %d outside 1..%d", nframes, e->max_batch);
-    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (e->pend_count == kDepth) return fail("%d async extracts are already in flight: synchronise first", kDepth);
     HIP_TRY(hipSetDevice(e->device));
+    return 0;
+}
+
+void push_pending(vmaf_hip_engine *e, int nframes, int continue_sequence, double *atoms_out)
+{
+    vmaf_hip_engine::Pending &p = e->pend[(e->pend_head + e->pend_count) % kDepth];
+    p.frames = nframes;
+    p.first_has_motion = continue_sequence != 0;
+    p.out = atoms_out;
+    ++e->pend_count;
+}
+
+// Wait for the oldest call in flight and finish its frames on the host.
+int finish_oldest(vmaf_hip_engine *e)
+{
+    const int slot = e->pend_head;
+    const vmaf_hip_engine::Pending &p = e->pend[slot];
+    HIP_TRY(hipEventSynchronize(e->ev_done[slot]));
+    const double *sums = e->sums_host[slot];
+    for (int f = 0; f < p.frames; ++f)
+        finish_atoms(e, sums + (size_t)f * VK_NSUMS, f > 0 || p.first_has_motion, p.out + (size_t)f * VMAF_HIP_ATOMS);
+    if (e->m_psnr || e->m_ssim || e->m_ms) {
+        e->metrics.resize((size_t)p.frames * VMAF_HIP_METRICS);
+        for (int f = 0; f < p.frames; ++f)
+            finish_metrics(e, sums + (size_t)f * VK_NSUMS, e->metrics.data() + (size_t)f * VMAF_HIP_METRICS);
+    }
+    e->last_slot = slot;
+    e->pend_head = (e->pend_head + 1) % kDepth;
+    --e->pend_count;
     return 0;
 }
 
@@ -336,9 +369,11 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     hipEvent_t *evs[] = { &e->ev_in, &e->ev_adm, &e->ev_mot };
     for (auto ev : evs)
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
-    hipEvent_t *tevs[] = { &e->ev_t0, &e->ev_t1, &e->ev_k0, &e->ev_k1 };
-    for (auto ev : tevs)
-        if (hipEventCreate(ev) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
+    for (int i = 0; i < kDepth; ++i) {
+        hipEvent_t *tevs[] = { &e->ev_t0[i], &e->ev_t1[i], &e->ev_k0[i], &e->ev_k1[i], &e->ev_done[i] };
+        for (auto ev : tevs)
+            if (hipEventCreate(ev) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
+    }
 
     for (int s = 1; s < 4 && !rc; ++s) {
         rc |= alloc_planes(&e->vif_ref[s], B * e->vw[s] * e->vh[s]);
@@ -361,7 +396,8 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     e->part_total = off;
     if (!rc && hipMalloc((void **)&e->partials, off * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(partials) failed");
     if (!rc && hipMalloc((void **)&e->sums_dev, B * VK_NSUMS * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(sums) failed");
-    if (!rc && hipHostMalloc((void **)&e->sums_host, B * VK_NSUMS * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail("hipHostMalloc failed");
+    for (int i = 0; i < kDepth && !rc; ++i)
+        if (hipHostMalloc((void **)&e->sums_host[i], B * VK_NSUMS * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail("hipHostMalloc failed");
     if (rc) return cleanup();
     *out = e;
     return 0;
@@ -384,9 +420,13 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     if (e->ev_iqa) (void)hipEventDestroy(e->ev_iqa);
     if (e->s_iqa && e->s_iqa != e->s_main) (void)hipStreamDestroy(e->s_iqa);
     (void)hipFree(e->partials); (void)hipFree(e->sums_dev);
-    if (e->sums_host) (void)hipHostFree(e->sums_host);
-    hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_t0, e->ev_t1, e->ev_k0, e->ev_k1 };
+    hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot };
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
+    for (int i = 0; i < kDepth; ++i) {
+        if (e->sums_host[i]) (void)hipHostFree(e->sums_host[i]);
+        hipEvent_t tevs[] = { e->ev_t0[i], e->ev_t1[i], e->ev_k0[i], e->ev_k1[i], e->ev_done[i] };
+        for (auto ev : tevs) if (ev) (void)hipEventDestroy(ev);
+    }
     if (!e->serial) { if (e->s_adm) (void)hipStreamDestroy(e->s_adm); if (e->s_mot) (void)hipStreamDestroy(e->s_mot); }
     if (e->s_main) (void)hipStreamDestroy(e->s_main);
     delete e;
@@ -403,7 +443,7 @@ int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order)
 int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit)
 {
     if (!e) return fail("null engine");
-    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
     HIP_TRY(hipSetDevice(e->device));
     const size_t B = (size_t)e->max_batch;
     if (do_ssim) {
@@ -461,7 +501,7 @@ int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes)
 {
     if (!e || !out) return fail("null argument");
     if (!(e->m_psnr || e->m_ssim || e->m_ms)) return fail("no metric enabled on this engine");
-    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (nframes < 0 || (size_t)nframes * VMAF_HIP_METRICS > e->metrics.size()) return fail("the last call scored %zu frames, %d asked for", e->metrics.size() / VMAF_HIP_METRICS, nframes);
     std::copy(e->metrics.begin(), e->metrics.begin() + (size_t)nframes * VMAF_HIP_METRICS, out);
     return 0;
@@ -471,17 +511,18 @@ int vmaf_hip_engine_sync(vmaf_hip_engine *e)
 {
     if (!e) return fail("null engine");
     HIP_TRY(hipSetDevice(e->device));
+    while (e->pend_count)
+        if (finish_oldest(e)) return 1;
     HIP_TRY(hipStreamSynchronize(e->s_main));
-    for (int f = 0; f < e->pend_frames; ++f)
-        finish_atoms(e, e->sums_host + (size_t)f * VK_NSUMS, f > 0 || e->pend_first_has_motion,
-                     e->pend_out + (size_t)f * VMAF_HIP_ATOMS);
-    if (e->pend_frames && (e->m_psnr || e->m_ssim || e->m_ms)) {
-        e->metrics.resize((size_t)e->pend_frames * VMAF_HIP_METRICS);
-        for (int f = 0; f < e->pend_frames; ++f)
-            finish_metrics(e, e->sums_host + (size_t)f * VK_NSUMS, e->metrics.data() + (size_t)f * VMAF_HIP_METRICS);
-    }
-    e->pend_frames = 0;
     return 0;
+}
+
+int vmaf_hip_engine_sync_oldest(vmaf_hip_engine *e)
+{
+    if (!e) return fail("null engine");
+    if (!e->pend_count) return fail("no async extract in flight");
+    HIP_TRY(hipSetDevice(e->device));
+    return finish_oldest(e);
 }
 
 int vmaf_hip_extract_device_async(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
@@ -489,9 +530,7 @@ int vmaf_hip_extract_device_async(vmaf_hip_engine *e, const float *d_ref, const 
 {
     if (check_call(e, d_ref, d_dis, nframes, atoms_out)) return 1;
     if (enqueue_batch(e, d_ref, d_dis, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence)) return 1;
-    e->pend_frames = nframes;
-    e->pend_first_has_motion = continue_sequence != 0;
-    e->pend_out = atoms_out;
+    push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
 
@@ -518,9 +557,7 @@ int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const fl
                                  hipMemcpyHostToDevice, e->s_main));
     }
     if (enqueue_batch(e, e->stage_ref, e->stage_dis, dense_row, dense_frame, nframes, continue_sequence)) return 1;
-    e->pend_frames = nframes;
-    e->pend_first_has_motion = continue_sequence != 0;
-    e->pend_out = atoms_out;
+    push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
 
@@ -550,9 +587,7 @@ static int widen_and_enqueue(vmaf_hip_engine *e, const void *d_ref, const void *
     HIP_TRY(vk_launch_widen(d_dis, bps, rs, fs, e->stage_dis, e->w, e->h, nframes, e->s_main));
     const size_t dense_row = (size_t)e->w * 4, dense_frame = dense_row * e->h;
     if (enqueue_batch(e, e->stage_ref, e->stage_dis, dense_row, dense_frame, nframes, continue_sequence)) return 1;
-    e->pend_frames = nframes;
-    e->pend_first_has_motion = continue_sequence != 0;
-    e->pend_out = atoms_out;
+    push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
 
@@ -611,7 +646,7 @@ int vmaf_hip_extract_device_raw(vmaf_hip_engine *e, const void *d_ref, const voi
 int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int bytes_per_sample, size_t row_stride_bytes)
 {
     if (!e || !h_ref) return fail("null argument");
-    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (check_raw(e, bytes_per_sample, row_stride_bytes, 0, 1)) return 1;
     HIP_TRY(hipSetDevice(e->device));
     // the float staging plane doubles as the landing area of the raw rows (its tail) - one frame only
@@ -634,7 +669,7 @@ void vmaf_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t row_stride_bytes)
 {
     if (!e || !d_ref) return fail("null argument");
-    if (e->pend_frames) return fail("a previous async extract has not been synchronised");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (row_stride_bytes % 4 || row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
     HIP_TRY(hipSetDevice(e->device));
     // one-frame motion launch without predecessor: only its carry_out side effect is used
@@ -689,7 +724,7 @@ double vmaf_hip_last_kernel_ms(vmaf_hip_engine *e, int which)
     if (!e) return -1.0;
     if (!e->timed) { e->timed = true; return -1.0; }          // first call arms the events for the next batch
     float ms = -1.0f;
-    hipError_t err = which == 1 ? hipEventElapsedTime(&ms, e->ev_k0, e->ev_k1) : hipEventElapsedTime(&ms, e->ev_t0, e->ev_t1);
+    hipError_t err = which == 1 ? hipEventElapsedTime(&ms, e->ev_k0[e->last_slot], e->ev_k1[e->last_slot]) : hipEventElapsedTime(&ms, e->ev_t0[e->last_slot], e->ev_t1[e->last_slot]);
     return err == hipSuccess ? (double)ms : -1.0;
 }
 
