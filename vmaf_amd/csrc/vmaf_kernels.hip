@@ -263,6 +263,7 @@ __device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float
 // horizontal pass 32 rows * (48/6) strips = 256 items, so all four waves work in both phases; 48 divides
 // every level of the 1080p / 4K pyramids (1920, 960, 480, 240).
 constexpr int VIF_TW = 48, VIF_TH = 32, VIF_THREADS = 256, VIF_SV = 8, VIF_SH = 6;
+constexpr int VIF_BLOCKS_PER_CU = 4;                          // 32 KB LDS and <= 128 VGPRs per workgroup
 
 template <int FW> struct VifGeom {
     static constexpr int R = FW / 2;
@@ -280,7 +281,8 @@ template <int FW> struct VifGeom {
     static constexpr int DSH = 3;                             // decimated outputs per thread, horizontal pass
     static_assert(2 * (VIF_TH / 2) * (VIF_TW / 2 / DSH) == VIF_THREADS && (VIF_TW / 2) % DSH == 0, "one decimation strip per thread");
     static constexpr int IN_FLOATS = 2 * IH * IW;
-    static constexpr int V_FLOATS = 5 * VIF_TH * VS;
+    static constexpr int VQ = 3;                              // planes of vertical results in LDS at a time (of 5: two rounds)
+    static constexpr int V_FLOATS = VQ * VIF_TH * VS;
     static constexpr int SMEM_FLOATS = (IN_FLOATS > V_FLOATS ? IN_FLOATS : V_FLOATS);
     static_assert(VW * (VIF_TH / VIF_SV) <= VIF_THREADS, "one vertical item per thread");
     static_assert(VW % 2 == 0 && NV % 2 == 0 && VIF_SH % 2 == 0, "float2 reads");
@@ -351,7 +353,7 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
 // picks its order exactly as convolution_f32_avx_s_1d does (convolution_avx.c:806-836); both write
 // partial[frame][tile] and the decimated planes of their own tiles.
 template <int FW, bool OFFSET, int ORDER, bool BORDER>
-__global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+__global__ __launch_bounds__(VIF_THREADS, VIF_BLOCKS_PER_CU) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                                size_t frame_stride, int row_stride, int w, int h,
                                                                double *__restrict__ partial,
                                                                float *__restrict__ oref, float *__restrict__ odis,
@@ -456,15 +458,8 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
             if (x0 / 2 + ox0 + o < ow && gy < oh) dst[o] = val;
         }
     }
-    if (vactive) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q)
-#pragma unroll
-            for (int o = 0; o < VIF_SV; ++o) vout[(q * VIF_TH + vs * VIF_SV + o) * VS + vc] = vo[q][o];
-    }
-    __syncthreads();
-
-    // ---- horizontal pass + statistic: one row, VIF_SH output columns
+    // ---- horizontal pass: one row, VIF_SH output columns.  The five planes of vertical results go through LDS in
+    // two rounds ({mu1, mu2, xx}, then {yy, xy}): 3 planes of LDS instead of 5 let four workgroups share a CU.
     double acc[2] = { 0.0, 0.0 };
     {
         const int row = tid % VIF_TH, strip = tid / VIF_TH;
@@ -479,16 +474,32 @@ __global__ __launch_bounds__(VIF_THREADS, 3) void vif_stat_kernel(const float *_
             }
         }
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            float v[G::NV];
-            const float2 *p = reinterpret_cast<const float2 *>(vout + (q * VIF_TH + row) * VS + strip * VIF_SH);
+        for (int round = 0; round < 2; ++round) {
+            constexpr int VQ = G::VQ;
+            const int q0 = round * VQ, nq = round == 0 ? VQ : 5 - VQ;
+            if (round) __syncthreads();                       // round 0 fully read
+            if (vactive) {
 #pragma unroll
-            for (int m = 0; m < G::NV2; ++m) {
-                const float2 f2 = p[m];
-                v[2 * m] = f2.x; v[2 * m + 1] = f2.y;
+                for (int q = 0; q < VQ; ++q)
+                    if (q < nq) {
+#pragma unroll
+                        for (int o = 0; o < VIF_SV; ++o) vout[(q * VIF_TH + vs * VIF_SV + o) * VS + vc] = vo[q0 + q][o];
+                    }
             }
-            if (BORDER) taps_window_sel<FW, VIF_SH>(v, ho[q], hmask);
-            else taps_window<FW, VIF_SH, ORDER>(v, ho[q]);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < VQ; ++q)
+                if (q < nq) {
+                    float v[G::NV];
+                    const float2 *p = reinterpret_cast<const float2 *>(vout + (q * VIF_TH + row) * VS + strip * VIF_SH);
+#pragma unroll
+                    for (int m = 0; m < G::NV2; ++m) {
+                        const float2 f2 = p[m];
+                        v[2 * m] = f2.x; v[2 * m + 1] = f2.y;
+                    }
+                    if (BORDER) taps_window_sel<FW, VIF_SH>(v, ho[q0 + q], hmask);
+                    else taps_window<FW, VIF_SH, ORDER>(v, ho[q0 + q]);
+                }
         }
         const int gy = y0 + row;
 #pragma unroll
