@@ -474,9 +474,9 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_BLOCKS_PER_CU) void vif_stat_kerne
             }
         }
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
+        for (int round = 0; round < (5 + G::VQ - 1) / G::VQ; ++round) {
             constexpr int VQ = G::VQ;
-            const int q0 = round * VQ, nq = round == 0 ? VQ : 5 - VQ;
+            const int q0 = round * VQ, nq = 5 - q0 < VQ ? 5 - q0 : VQ;
             if (round) __syncthreads();                       // round 0 fully read
             if (vactive) {
 #pragma unroll
