@@ -142,10 +142,13 @@ int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int byt
  * the PSNR peak and cap (255.75 / 72 instead of 255 / 60, combo.c:171-186).  Call before the first extract, or between
  * synchronised calls.  SSIM at decimation factor 1 (min(w,h) < 384) and MS-SSIM need dense input planes.
  * vmaf_hip_engine_get_metrics copies the metrics of the frames of the last synchronised extract call:
- * out[nframes][VMAF_HIP_METRICS] = psnr, ssim, ms_ssim (0 where not enabled).
+ * out[nframes][VMAF_HIP_METRICS] = psnr, ssim, ms_ssim, ansnr, anpsnr (0 where not enabled).
+ * vmaf_hip_engine_enable_ansnr adds ANSNR / ANPSNR (feature/src/ansnr.c:44-104, the atoms `ansnr` and `anpsnr` of
+ * feature/src/all.c:148-176), computed like every caller of compute_ansnr does on the planes after the -128 offset.
  */
-#define VMAF_HIP_METRICS 3
+#define VMAF_HIP_METRICS 5
 int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit);
+int vmaf_hip_engine_enable_ansnr(vmaf_hip_engine *e, int ten_bit);
 int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes);
 
 /*

@@ -59,6 +59,7 @@ def lib():
         L.oracle_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _dp]
         L.oracle_ms_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.oracle_ssim_scale.argtypes = [C.c_int, C.c_int]
+        L.oracle_ansnr.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _dp, _dp]
         _lib = L
     return _lib
 
@@ -82,6 +83,8 @@ def ref_lib():
                 R.compute_psnr.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_double, C.c_double]
                 R.compute_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
                 R.compute_ms_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+            if hasattr(R, "compute_ansnr"):
+                R.compute_ansnr.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double]
             _ref = R
     return _ref
 
@@ -345,3 +348,22 @@ def ref_ms_ssim(ref_raw, dis_raw):
     assert R.compute_ms_ssim(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(s), l.ctypes.data_as(_dp), c.ctypes.data_as(_dp),
                              st.ctypes.data_as(_dp)) == 0
     return s.value, np.concatenate([l, c, st])
+
+
+def ansnr(ref_raw, dis_raw, bits=8):
+    """-> (ansnr, anpsnr) of the planes after the -128 offset every caller applies (ansnr.c:174-177, all.c:128-129)."""
+    r, d = _f32(ref_raw) + np.float32(-128), _f32(dis_raw) + np.float32(-128)
+    h, w = r.shape
+    a, b = C.c_double(), C.c_double()
+    lib().oracle_ansnr(_ptr(r), _ptr(d), w, h, w, *_peak(bits), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def ref_ansnr(ref_raw, dis_raw, bits=8):
+    R = ref_lib()
+    r, sb = _padded(np.asarray(ref_raw, np.float32) + np.float32(-128))
+    d, _ = _padded(np.asarray(dis_raw, np.float32) + np.float32(-128))
+    h, w = np.asarray(ref_raw).shape
+    a, b = C.c_double(), C.c_double()
+    assert R.compute_ansnr(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(a), C.byref(b), *_peak(bits)) == 0
+    return a.value, b.value

@@ -228,3 +228,60 @@ int oracle_ms_ssim(const float *ref, const float *cmp, int w, int h, int stride,
     *score = msssim;
     return 0;
 }
+
+/* ---------------------------------------------------------------- ANSNR (feature/src/ansnr.c:44-104, ansnr_tools.c)
+ * 2-D filter path (ANSNR_OPT_FILTER_1D is not defined, ansnr_options.h): ref through the 3x3 binomial, dis through
+ * the 5x5 kernel, mirrored borders (-i / 2n-i-1), float accumulation per kernel row then over rows
+ * (ansnr_tools.c:159-199); sig = sum ref_filtr^2, noise = sum (ref_filtr - dis_filtd)^2 as float row sums
+ * (ansnr_tools.c:60-88).  Every caller hands in the planes AFTER the -128 offset (ansnr.c:174-177, all.c:128-129). */
+static const float g_ansnr_ref[9] = {
+    1.0 / 16.0, 2.0 / 16.0, 1.0 / 16.0, 2.0 / 16.0, 4.0 / 16.0, 2.0 / 16.0, 1.0 / 16.0, 2.0 / 16.0, 1.0 / 16.0 };
+static const float g_ansnr_dis[25] = {
+    2.0 / 571.0,  7.0 / 571.0,  12.0 / 571.0,  7.0 / 571.0,  2.0 / 571.0,
+    7.0 / 571.0,  31.0 / 571.0, 52.0 / 571.0,  31.0 / 571.0, 7.0 / 571.0,
+    12.0 / 571.0, 52.0 / 571.0, 127.0 / 571.0, 52.0 / 571.0, 12.0 / 571.0,
+    7.0 / 571.0,  31.0 / 571.0, 52.0 / 571.0,  31.0 / 571.0, 7.0 / 571.0,
+    2.0 / 571.0,  7.0 / 571.0,  12.0 / 571.0,  7.0 / 571.0,  2.0 / 571.0 };
+
+static void ansnr_filter2d(const float *f, int fw, const float *src, float *dst, int w, int h, int stride)
+{
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            float accum = 0;
+            for (int fi = 0; fi < fw; ++fi) {
+                float inner = 0;
+                for (int fj = 0; fj < fw; ++fj) {
+                    int ii = i - fw / 2 + fi, jj = j - fw / 2 + fj;
+                    if (ii < 0) ii = -ii; else if (ii >= h) ii = 2 * h - ii - 1;
+                    if (jj < 0) jj = -jj; else if (jj >= w) jj = 2 * w - jj - 1;
+                    inner += f[fi * fw + fj] * src[ii * stride + jj];
+                }
+                accum += inner;
+            }
+            dst[i * w + j] = accum;
+        }
+}
+
+int oracle_ansnr(const float *ref_off, const float *dis_off, int w, int h, int stride, double peak, double psnr_max,
+                 double *score, double *score_psnr)
+{
+    float *rf = malloc(sizeof(float) * w * h), *df = malloc(sizeof(float) * w * h);
+    ansnr_filter2d(g_ansnr_ref, 3, ref_off, rf, w, h, stride);
+    ansnr_filter2d(g_ansnr_dis, 5, dis_off, df, w, h, stride);
+    float sig = 0, noise = 0;
+    for (int i = 0; i < h; ++i) {
+        float si = 0, ni = 0;
+        for (int j = 0; j < w; ++j) {
+            const float r = rf[i * w + j], d = df[i * w + j];
+            si += r * r;
+            ni += (r - d) * (r - d);
+        }
+        sig += si; noise += ni;
+    }
+    free(rf); free(df);
+    *score = noise == 0 ? psnr_max : 10.0 * log10(sig / noise);
+    const double eps = 1e-10;
+    const double v = 10 * log10(peak * peak * w * h / (noise > eps ? noise : eps));
+    *score_psnr = v < psnr_max ? v : psnr_max;
+    return 0;
+}

@@ -65,6 +65,8 @@ double oracle_psnr(const float *ref, const float *dis, int w, int h, int stride,
 int oracle_ssim_scale(int w, int h);
 int oracle_ssim(const float *ref, const float *cmp, int w, int h, int stride, double out[4]);           /* ssim, l, c, s */
 int oracle_ms_ssim(const float *ref, const float *cmp, int w, int h, int stride, double *score, double *out_lcs /* 15 or NULL */);
+int oracle_ansnr(const float *ref_off, const float *dis_off, int w, int h, int stride, double peak, double psnr_max,
+                 double *score, double *score_psnr);
 const float *oracle_ssim_window(void);      /* 11 taps */
 const float *oracle_ms_ssim_lpf(void);      /* 9 x 9 */
 

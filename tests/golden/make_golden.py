@@ -59,6 +59,15 @@ EXEC = {
     "metrics_tenbit": ("c320x180_10bit", "yuv420p10le", "model/vmaf_v0.6.1.pkl", ["--psnr", "--ssim", "--ms-ssim"]),
     "psnr_only": ("c64x48", "yuv420p", "model/vmaf_v0.6.1.pkl", ["--psnr"]),
 }
+# name -> (app, clip, pixel format) for the per-feature tool
+FEATURE_TOOL = {
+    "all": ("all", "c576x324_cut", "yuv420p"),
+    "all_tenbit": ("all", "c320x180_10bit", "yuv444p10le"),
+    "adm": ("adm", "c64x48", "yuv420p"),
+    "vif": ("vif", "c64x48", "yuv422p"),
+    "motion": ("motion", "c576x324_cut", "yuv420p"),
+    "ansnr": ("ansnr", "c96x64_strong", "yuv420p"),
+}
 IMAGES = ["100007", "100039"]      # python/test/resource/test_image_yuv/<n>.yuv vs <n>_noisy.yuv, 481x321 yuv444p
 
 
@@ -113,6 +122,20 @@ def main():
         res = run_exec("yuv444p", 481, 321, f"{img_dir}/{n}.yuv", f"{img_dir}/{n}_noisy.yuv", "model/vmaf_v0.6.1.pkl", [])
         ex[f"image_{n}"] = dict(clip=f"images/{n}", fmt="yuv444p", model="model/vmaf_v0.6.1.pkl", args=[], **res)
     json.dump(ex, open(os.path.join(HERE, "exec.json"), "w"), indent=0)
+
+    # the reference's per-feature tool feature/vmaf (oracle/_ref/vmaf, `make -C oracle ref_feature_tool`): stdout as is
+    tool = os.path.join(ROOT, "oracle", "_ref", "vmaf")
+    ft = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, (app, clip, fmt) in FEATURE_TOOL.items():
+            r, d, bits = clip_arrays(clip)
+            rp, dp = os.path.join(td, "ref.yuv"), os.path.join(td, "dis.yuv")
+            synth.write_yuv(rp, r, fmt)
+            synth.write_yuv(dp, d, fmt)
+            F, h, w = r.shape
+            out = subprocess.run([tool, app, fmt, rp, dp, str(w), str(h)], capture_output=True, text=True, check=True).stdout
+            ft[name] = dict(app=app, clip=clip, fmt=fmt, stdout=out)
+    json.dump(ft, open(os.path.join(HERE, "feature_tool.json"), "w"), indent=0)
 
     rng = np.random.default_rng(7)
     sv = {}

@@ -150,3 +150,34 @@ def test_raw_and_fp32_callbacks_give_identical_logs(name, tmp_path):
         assert p.returncode == 0, p.stderr + p.stdout
         logs.append(json.load(open(log))["frames"])
     assert logs[0] == logs[1] and len(logs[0]) == len(case["frames"])
+
+
+FEATURE_TOOL = json.load(open(os.path.join(GOLD, "feature_tool.json")))
+
+
+@pytest.mark.parametrize("name", sorted(FEATURE_TOOL))
+def test_feature_tool_speaks_the_reference_grammar(name, tmp_path):
+    """vmaf_amd/vmaf = the reference's per-feature tool `feature/vmaf app fmt ref dis w h` (vmaf_main.c): the same lines
+    in the same order ("<atom>: <frame> <%f>", all.c:138-226) as the reference tool printed for the same files
+    (tests/golden/feature_tool.json), values within 1e-4 absolute / 2e-6 relative (plane sums are reduced in fp64 here)."""
+    case = FEATURE_TOOL[name]
+    kw = dict(ATOMS[case["clip"]]["params"])
+    bits = kw.pop("bits", 8)
+    if "cuts" in kw:
+        kw["cuts"] = tuple(kw["cuts"])
+    r, d = synth.make_clip(bits=bits, **kw)
+    rp, dp = str(tmp_path / "ref.yuv"), str(tmp_path / "dis.yuv")
+    synth.write_yuv(rp, r, case["fmt"])
+    synth.write_yuv(dp, d, case["fmt"])
+    p = subprocess.run([os.path.join(ROOT, "vmaf_amd", "vmaf"), case["app"], case["fmt"], rp, dp, str(r.shape[2]), str(r.shape[1])],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr + p.stdout
+    got, want = p.stdout.splitlines(), case["stdout"].splitlines()
+    assert len(got) == len(want)
+    for g, w_ in zip(got, want):
+        gk, gf, gv = g.split()
+        wk, wf, wv = w_.split()
+        assert (gk, gf) == (wk, wf), (g, w_)
+        assert abs(float(gv) - float(wv)) <= 1e-4 + 2e-6 * abs(float(wv)), (g, w_)
+    # usage errors: exit 2 (vmaf_main.c:161-176)
+    assert subprocess.run([os.path.join(ROOT, "vmaf_amd", "vmaf"), "all"], capture_output=True).returncode == 2

@@ -237,7 +237,7 @@ def test_psnr_ssim_ms_ssim_match_oracle(bits, w, h):
         assert np.array_equal(e.metrics, got)          # raw ingest: same planes, same metrics
     with vmaf_amd.Engine(w, h, max_batch=2) as e:      # the metrics do not disturb the VMAF atoms
         assert np.array_equal(e.extract(ref, dis), atoms)
-    assert got.shape == (frames, 3)
+    assert got.shape == (frames, vmaf_amd.binding.N_METRICS)
     for f in range(frames):
         want = (oracle.psnr(ref[f], dis[f], bits), oracle.ssim(ref[f], dis[f])[0], oracle.ms_ssim(ref[f], dis[f])[0])
         assert abs(got[f, 0] - want[0]) < 1e-9, (f, got[f], want)
@@ -251,7 +251,7 @@ def test_metrics_identical_frames_and_too_small_frames():
         e.enable_metrics()
         e.extract(ref, ref)
         assert np.all(e.metrics[:, 0] == 60.0)         # psnr cap for 8-bit (psnr.c:54, combo.c:174)
-        assert np.allclose(e.metrics[:, 1:], 1.0, atol=1e-6)
+        assert np.allclose(e.metrics[:, 1:3], 1.0, atol=1e-6)
     with vmaf_amd.Engine(160, 96) as e:                # 96 -> 48 -> 24 -> 12 -> 6 < 11: "scale below 1x1" (ms_ssim.c:172-177)
         with pytest.raises(vmaf_amd.VmafHipError, match="scale below 1x1"):
             e.enable_metrics()
@@ -301,3 +301,23 @@ def test_two_async_calls_in_flight():
         e.extract_device(tr[4:6], td[4:6], 2, continue_sequence=True, out=got[2], sync=False)
         e.sync()
         assert np.array_equal(got.reshape(6, 20), want)
+
+
+@pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 101, 75), (10, 320, 180)])
+def test_ansnr_matches_oracle(bits, w, h):
+    """feature/src/ansnr.c through the GPU (the `ansnr` / `anpsnr` atoms of feature/src/all.c) against the C
+    restatement, which is bit-exact against the compiled reference (tests/test_oracle_vs_ref.py)."""
+    r, d = synth.make_clip(w, h, 3, bits=bits, seed=9 + w)
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:
+        e.enable_ansnr(ten_bit=bits == 10)
+        e.extract(ref, dis)
+        got = e.metrics.copy()
+    for f in range(3):
+        want = oracle.ansnr(ref[f], dis[f], bits)
+        assert abs(got[f, 3] - want[0]) < 1e-4 and abs(got[f, 4] - want[1]) < 1e-4, (f, got[f], want)
+    with vmaf_amd.Engine(w, h) as e:
+        e.enable_ansnr(ten_bit=bits == 10)
+        e.extract(ref[:1], ref[:1])
+        want = oracle.ansnr(ref[0], ref[0], bits)        # identical planes still differ after the two different filters
+        assert abs(e.metrics[0, 3] - want[0]) < 1e-4 and abs(e.metrics[0, 4] - want[1]) < 1e-4

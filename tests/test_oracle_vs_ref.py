@@ -61,3 +61,10 @@ def test_psnr_ssim_ms_ssim_bit_exact(w, h, bits):
     got, want = oracle.ms_ssim(r, d), oracle.ref_ms_ssim(r, d)
     assert got[0] == want[0] and np.array_equal(got[1], want[1])
     assert oracle.psnr(r, r, bits) == (60.0 if bits == 8 else 72.0)
+
+
+@pytest.mark.parametrize("w,h,bits", [(576, 324, 8), (101, 75, 8), (320, 180, 10)])
+def test_ansnr_bit_exact(w, h, bits):
+    r, d = synth.make_clip(w, h, 1, bits=bits, seed=w)
+    r, d = synth.to_luma_f32(r, bits)[0], synth.to_luma_f32(d, bits)[0]
+    assert oracle.ansnr(r, d, bits) == oracle.ref_ansnr(r, d, bits)

@@ -18,7 +18,7 @@ ATOM_NAMES = (["adm_num", "adm_den"] +
               [f"vif_{k}_scale{s}" for s in range(4) for k in ("num", "den")] +
               ["vif"])
 N_ATOMS = 20
-N_METRICS = 3          # psnr, ssim, ms_ssim (vmaf_hip_engine_get_metrics)
+N_METRICS = 5          # psnr, ssim, ms_ssim, ansnr, anpsnr (vmaf_hip_engine_get_metrics)
 
 
 class VmafHipError(RuntimeError):
@@ -59,6 +59,7 @@ def load_library():
         getattr(L, name).argtypes = [vp, vp, vp, i, sz, sz, i, i, _dp]
     L.vmaf_hip_motion_seed_host_raw.argtypes = [vp, vp, i, sz]
     L.vmaf_hip_engine_enable_metrics.argtypes = [vp, i, i, i, i]
+    L.vmaf_hip_engine_enable_ansnr.argtypes = [vp, i]
     L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_engine_sync_oldest.argtypes = [vp]
@@ -121,6 +122,12 @@ class Engine:
         if self.L.vmaf_hip_engine_enable_metrics(self._h, int(psnr), int(ssim), int(ms_ssim), int(ten_bit)):
             raise VmafHipError(_err(self.L))
         self._metrics_on = bool(psnr or ssim or ms_ssim)
+
+    def enable_ansnr(self, ten_bit=False):
+        """ANSNR / ANPSNR (feature/src/ansnr.c) as columns 3 and 4 of self.metrics."""
+        if self.L.vmaf_hip_engine_enable_ansnr(self._h, int(ten_bit)):
+            raise VmafHipError(_err(self.L))
+        self._metrics_on = True
 
     def _collect_metrics(self, rows, n):
         if self._metrics_on:

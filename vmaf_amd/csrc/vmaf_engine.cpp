@@ -86,7 +86,7 @@ struct vmaf_hip_engine {
     int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
 
     // optional metrics (combo.c:168-230): PSNR, SSIM, MS-SSIM on the un-offset planes
-    bool m_psnr = false, m_ssim = false, m_ms = false;
+    bool m_psnr = false, m_ssim = false, m_ms = false, m_ansnr = false;
     double psnr_peak = 255.0, psnr_max = 60.0;
     hipStream_t s_iqa = nullptr;
     hipEvent_t ev_iqa = nullptr;
@@ -94,8 +94,8 @@ struct vmaf_hip_engine {
     float *ssim_ref = nullptr, *ssim_dis = nullptr;
     int ms_w[5] = {}, ms_h[5] = {};
     float *ms_ref[5] = {}, *ms_dis[5] = {};        // [1..4]
-    size_t part_off_psnr = 0, part_off_ssim = 0, part_off_ms[5] = {};
-    int tiles_psnr = 0, tiles_ssim = 0, tiles_ms[5] = {};
+    size_t part_off_psnr = 0, part_off_ssim = 0, part_off_ms[5] = {}, part_off_ansnr = 0;
+    int tiles_psnr = 0, tiles_ssim = 0, tiles_ms[5] = {}, tiles_ansnr = 0;
     std::vector<double> metrics;                   // [frames of the last synchronised call][VMAF_HIP_METRICS]
 
     // asynchronous calls in flight (at most kDepth: the host can enqueue batch k+1 while batch k runs, so the GPU
@@ -144,7 +144,13 @@ void finish_atoms(const vmaf_hip_engine *e, const double *s, bool has_motion, do
 // psnr.c:51-55, ssim_tools.c:236-241, ms_ssim.c:268-312 from the reduced sums of one frame
 void finish_metrics(const vmaf_hip_engine *e, const double *s, double *m)
 {
-    m[0] = m[1] = m[2] = 0.0;
+    for (int k = 0; k < VMAF_HIP_METRICS; ++k) m[k] = 0.0;
+    if (e->m_ansnr) {                                                   // ansnr.c:92-98
+        const float sig = (float)s[58], noise = (float)s[59];
+        m[3] = noise == 0 ? e->psnr_max : 10.0 * std::log10(sig / noise);
+        const double eps = 1e-10;
+        m[4] = std::min(10 * std::log10(e->psnr_peak * e->psnr_peak * e->w * e->h / std::max((double)noise, eps)), e->psnr_max);
+    }
     if (e->m_psnr) {
         double noise = s[33];
         noise /= (e->w * e->h);
@@ -186,10 +192,11 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
 
     // ---- optional metrics on their own stream (combo.c:168-230: before the -128 offset, i.e. on the planes as given)
-    if (e->m_psnr || e->m_ssim || e->m_ms) {
+    if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) {
         hipStream_t q = e->s_iqa;
         HIP_TRY(hipStreamWaitEvent(q, e->ev_in, 0));
         if (e->m_psnr) HIP_TRY(vk_launch_psnr(d_ref, d_dis, fs, rs, e->w, e->h, nframes, e->partials + e->part_off_psnr, q));
+        if (e->m_ansnr) HIP_TRY(vk_launch_ansnr(d_ref, d_dis, fs, rs, e->w, e->h, nframes, e->partials + e->part_off_ansnr, q));
         if (e->m_ssim) {
             const float *sr = d_ref, *sd = d_dis;
             if (e->ssim_f > 1) {
@@ -255,7 +262,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     // ---- join, reduce, copy back
     HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_adm, 0));
     HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_mot, 0));
-    if (e->m_psnr || e->m_ssim || e->m_ms) HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_iqa, 0));
+    if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_iqa, 0));
     vk_reduce_table tab;
     int q = 0;
     for (int sc = 0; sc < 4; ++sc)
@@ -268,6 +275,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c, 0, 0 };
     for (int i = 0; i < 5; ++i)
         for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ms[i], e->m_ms ? e->tiles_ms[i] : 0, 4, c, 0, 0 };
+    for (int c = 0; c < 2; ++c) tab.d[q++] = { e->part_off_ansnr, e->m_ansnr ? e->tiles_ansnr : 0, 2, c, 0, 0 };
     HIP_TRY(vk_launch_reduce(e->partials, &tab, nframes, e->sums_dev, e->s_main));
     HIP_TRY(hipMemcpyAsync(e->sums_host[slot], e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
     if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1[slot], e->s_main));
@@ -303,7 +311,7 @@ int finish_oldest(vmaf_hip_engine *e)
     const double *sums = e->sums_host[slot];
     for (int f = 0; f < p.frames; ++f)
         finish_atoms(e, sums + (size_t)f * VK_NSUMS, f > 0 || p.first_has_motion, p.out + (size_t)f * VMAF_HIP_ATOMS);
-    if (e->m_psnr || e->m_ssim || e->m_ms) {
+    if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) {
         e->metrics.resize((size_t)p.frames * VMAF_HIP_METRICS);
         for (int f = 0; f < p.frames; ++f)
             finish_metrics(e, sums + (size_t)f * VK_NSUMS, e->metrics.data() + (size_t)f * VMAF_HIP_METRICS);
@@ -440,7 +448,19 @@ int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order)
     return 0;
 }
 
+static int enable_metrics_impl(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int do_ansnr, int ten_bit);
+
 int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit)
+{
+    return enable_metrics_impl(e, do_psnr, do_ssim, do_ms_ssim, e ? e->m_ansnr : 0, ten_bit);
+}
+
+int vmaf_hip_engine_enable_ansnr(vmaf_hip_engine *e, int ten_bit)
+{
+    return enable_metrics_impl(e, e ? e->m_psnr : 0, e ? e->m_ssim : 0, e ? e->m_ms : 0, 1, ten_bit);
+}
+
+static int enable_metrics_impl(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int do_ansnr, int ten_bit)
 {
     if (!e) return fail("null engine");
     if (e->pend_count) return fail("a previous async extract has not been synchronised");
@@ -481,6 +501,7 @@ int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim,
     if (!e->tiles_psnr) {
         e->tiles_psnr = vk_psnr_tiles(e->h); e->part_off_psnr = off; off += B * e->tiles_psnr;
     }
+    if (do_ansnr && !e->tiles_ansnr) { e->tiles_ansnr = vk_ansnr_tiles(e->w, e->h); e->part_off_ansnr = off; off += B * e->tiles_ansnr * 2; }
     if (do_ssim && !e->tiles_ssim) { e->tiles_ssim = vk_ssim_tiles(e->ssim_w, e->ssim_h); e->part_off_ssim = off; off += B * e->tiles_ssim * 4; }
     if (do_ms_ssim && !e->tiles_ms[0])
         for (int i = 0; i < 5; ++i) { e->tiles_ms[i] = vk_ssim_tiles(e->ms_w[i], e->ms_h[i]); e->part_off_ms[i] = off; off += B * e->tiles_ms[i] * 4; }
@@ -491,7 +512,7 @@ int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim,
         HIP_TRY(hipMalloc((void **)&e->partials, off * sizeof(double)));
         e->part_total = off;
     }
-    e->m_psnr = do_psnr != 0; e->m_ssim = do_ssim != 0; e->m_ms = do_ms_ssim != 0;
+    e->m_psnr = do_psnr != 0; e->m_ssim = do_ssim != 0; e->m_ms = do_ms_ssim != 0; e->m_ansnr = do_ansnr != 0;
     e->psnr_peak = ten_bit ? 255.75 : 255.0;                           // combo.c:171-186
     e->psnr_max = ten_bit ? 72.0 : 60.0;
     return 0;
@@ -500,7 +521,7 @@ int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim,
 int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes)
 {
     if (!e || !out) return fail("null argument");
-    if (!(e->m_psnr || e->m_ssim || e->m_ms)) return fail("no metric enabled on this engine");
+    if (!(e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr)) return fail("no metric enabled on this engine");
     if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (nframes < 0 || (size_t)nframes * VMAF_HIP_METRICS > e->metrics.size()) return fail("the last call scored %zu frames, %d asked for", e->metrics.size() / VMAF_HIP_METRICS, nframes);
     std::copy(e->metrics.begin(), e->metrics.begin() + (size_t)nframes * VMAF_HIP_METRICS, out);

@@ -13,7 +13,8 @@
 //   [33]     PSNR: sum (ref - dis)^2
 //   [34..37] SSIM: sum l*c*s, sum l, sum c, sum s over the valid window of the decimated planes
 //   [38..57] MS-SSIM scale 0..4: the same four sums each
-#define VK_NSUMS 58
+//   [58,59]  ANSNR: sig = sum ref_filtr^2, noise = sum (ref_filtr - dis_filtd)^2
+#define VK_NSUMS 60
 
 typedef struct {
     size_t offset;   // first double of this section in the partial buffer
@@ -57,6 +58,9 @@ hipError_t vk_launch_box_decimate(const float *src, size_t src_frame_stride, int
                                   int sw, int sh, int nframes, hipStream_t s);
 hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h,
                                   float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s);
+int vk_ansnr_tiles(int w, int h);
+hipError_t vk_launch_ansnr(const float *ref, const float *dis, size_t frame_stride, int row_stride, int w, int h, int nframes,
+                           double *partial, hipStream_t s);
 hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, double *partial, hipStream_t s);
 hipError_t vk_launch_reduce(const double *partial, const vk_reduce_table *tab, int nframes, double *sums, hipStream_t s);
 hipError_t vk_launch_svm(const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho, const double *x,

@@ -1021,6 +1021,60 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
     block_reduce_store<4, 4>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x) * 4);
 }
 
+// ANSNR (ansnr.c:44-104 with the 2-D filters of ansnr_tools.c:36-58, :159-199): ref through the 3x3 binomial, dis
+// through the 5x5 kernel, float sums per kernel row then over rows, mirrored borders; sig = sum ref_filtr^2,
+// noise = sum (ref_filtr - dis_filtd)^2.  Runs on the offset planes like every caller of compute_ansnr does.
+constexpr float kAnsnrRef[9] = { (float)(1.0 / 16.0), (float)(2.0 / 16.0), (float)(1.0 / 16.0), (float)(2.0 / 16.0), (float)(4.0 / 16.0),
+                                 (float)(2.0 / 16.0), (float)(1.0 / 16.0), (float)(2.0 / 16.0), (float)(1.0 / 16.0) };
+constexpr float kAnsnrDis[25] = {
+    (float)(2.0 / 571.0),  (float)(7.0 / 571.0),  (float)(12.0 / 571.0),  (float)(7.0 / 571.0),  (float)(2.0 / 571.0),
+    (float)(7.0 / 571.0),  (float)(31.0 / 571.0), (float)(52.0 / 571.0),  (float)(31.0 / 571.0), (float)(7.0 / 571.0),
+    (float)(12.0 / 571.0), (float)(52.0 / 571.0), (float)(127.0 / 571.0), (float)(52.0 / 571.0), (float)(12.0 / 571.0),
+    (float)(7.0 / 571.0),  (float)(31.0 / 571.0), (float)(52.0 / 571.0),  (float)(31.0 / 571.0), (float)(7.0 / 571.0),
+    (float)(2.0 / 571.0),  (float)(7.0 / 571.0),  (float)(12.0 / 571.0),  (float)(7.0 / 571.0),  (float)(2.0 / 571.0) };
+constexpr int AN_TW = 64, AN_TH = 16, AN_IW = AN_TW + 4, AN_IH = AN_TH + 4;
+
+__global__ __launch_bounds__(256) void ansnr_kernel(const float *__restrict__ ref, const float *__restrict__ dis, size_t frame_stride,
+                                                    int row_stride, int w, int h, double *__restrict__ partial)
+{
+    __shared__ float tr[AN_IH * AN_IW], td[AN_IH * AN_IW];
+    __shared__ double red[8];
+    const float *fr = ref + (size_t)blockIdx.z * frame_stride, *fd = dis + (size_t)blockIdx.z * frame_stride;
+    const int x0 = blockIdx.x * AN_TW, y0 = blockIdx.y * AN_TH;
+    for (int idx = threadIdx.x; idx < AN_IH * AN_IW; idx += 256) {
+        const int ly = idx / AN_IW, lx = idx - ly * AN_IW;
+        const size_t g = (size_t)mirror_idx(y0 - 2 + ly, h) * row_stride + mirror_idx(x0 - 2 + lx, w);
+        tr[idx] = fr[g] + -128.0f;                                   // offset_image, ansnr.c:174-177 / all.c:128-129
+        td[idx] = fd[g] + -128.0f;
+    }
+    __syncthreads();
+    double acc[2] = { 0.0, 0.0 };
+#pragma unroll
+    for (int it = 0; it < AN_TW * AN_TH / 256; ++it) {
+        const int ox = threadIdx.x & 63, oy = (threadIdx.x >> 6) + it * 4;
+        float rf = 0.0f, df = 0.0f;
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) {
+            float inner = kAnsnrRef[fi * 3] * tr[(oy + 1 + fi) * AN_IW + ox + 1];
+#pragma unroll
+            for (int fj = 1; fj < 3; ++fj) inner = inner + kAnsnrRef[fi * 3 + fj] * tr[(oy + 1 + fi) * AN_IW + ox + 1 + fj];
+            rf = fi == 0 ? inner : rf + inner;
+        }
+#pragma unroll
+        for (int fi = 0; fi < 5; ++fi) {
+            float inner = kAnsnrDis[fi * 5] * td[(oy + fi) * AN_IW + ox];
+#pragma unroll
+            for (int fj = 1; fj < 5; ++fj) inner = inner + kAnsnrDis[fi * 5 + fj] * td[(oy + fi) * AN_IW + ox + fj];
+            df = fi == 0 ? inner : df + inner;
+        }
+        if (x0 + ox < w && y0 + oy < h) {
+            acc[0] += (double)(rf * rf);
+            acc[1] += (double)((rf - df) * (rf - df));
+        }
+    }
+    block_reduce_store<2, 4>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x) * 2);
+}
+
 // ---------------------------------------------------------------- final reduction
 __global__ __launch_bounds__(256) void reduce_kernel(const double *__restrict__ partial, vk_reduce_table tab,
                                                      double *__restrict__ sums /* [frame][VK_NSUMS] */)
@@ -1180,6 +1234,16 @@ hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h,
 {
     const dim3 g((w - 10 + SS_TW - 1) / SS_TW, (h - 10 + SS_TH - 1) / SS_TH, nframes);
     ssim_stat_kernel<<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
+    return hipGetLastError();
+}
+
+int vk_ansnr_tiles(int w, int h) { return ((w + AN_TW - 1) / AN_TW) * ((h + AN_TH - 1) / AN_TH); }
+
+// un-offset planes in (the kernel applies the -128 every caller of compute_ansnr applies); 2 doubles per workgroup
+hipError_t vk_launch_ansnr(const float *ref, const float *dis, size_t frame_stride, int row_stride, int w, int h, int nframes,
+                           double *partial, hipStream_t s)
+{
+    ansnr_kernel<<<dim3((w + AN_TW - 1) / AN_TW, (h + AN_TH - 1) / AN_TH, nframes), 256, 0, s>>>(ref, dis, frame_stride, row_stride, w, h, partial);
     return hipGetLastError();
 }
 
