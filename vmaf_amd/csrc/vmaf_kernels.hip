@@ -213,6 +213,40 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *red /
     }
 }
 
+// Same result layout, but through LDS instead of 6 x 2 x K cross-lane shuffles per thread: every thread parks its K
+// values, K x 32 threads add 8 of them each in a fixed order and finish with a 32-lane shuffle tree.  Deterministic.
+// buf: K * NT doubles of LDS (may alias data that is dead after the leading barrier).
+template <int K, int NT>
+__device__ __forceinline__ void block_reduce_store_lds(double (&v)[K], double *buf, double *out)
+{
+    static_assert(NT == 256 && K * 32 <= NT, "256 threads, at most 8 values");
+    const int tid = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) buf[k * NT + tid] = v[k];
+    __syncthreads();
+    if (tid < K * 32) {
+        const int k = tid >> 5, j = tid & 31;
+        double s = buf[k * NT + j];
+#pragma unroll
+        for (int i = 1; i < NT / 32; ++i) s += buf[k * NT + j + 32 * i];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+        if (j == 0) out[k] = s;
+    }
+}
+
+// Buffer-addressed loads (cdna_hip_programming.md T8/T20): a 128-bit descriptor of one frame in SGPRs, a wave-uniform
+// byte offset in an SGPR and the per-lane byte offset in one VGPR - no 64-bit per-lane address arithmetic.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const float *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voffset_bytes, soffset_bytes, 0));
+}
+
 // ---------------------------------------------------------------- VIF statistic
 // feature/src/vif_tools.c:33-75
 __device__ __forceinline__ float log2f_approx(float x)
@@ -567,11 +601,13 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
         const int ty0 = half * ADM_RPT;
         const int iy0 = 2 * (cy0 - 1 + ty0) - 1;
         float pr[2 * ADM_RPT + 2], pd[2 * ADM_RPT + 2];
+        const unsigned frame_bytes = (unsigned)h * (unsigned)in_row_stride * 4u;
+        const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
 #pragma unroll
         for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
-            const size_t g = (size_t)mirror_idx(iy0 + k, h) * in_row_stride + xc;
-            pr[k] = fr[g];
-            pd[k] = fd[g];
+            const int roff = mirror_idx(iy0 + k, h) * in_row_stride * 4;   // wave-uniform: SGPR
+            pr[k] = buf_load(br, xc * 4, roff);
+            pd[k] = buf_load(bd, xc * 4, roff);
         }
         if (OFFSET) {
 #pragma unroll
@@ -723,9 +759,8 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
             }
         }
     }
-    __syncthreads();
     const size_t tile = (size_t)blockIdx.z * gridDim.x + tile_id;
-    block_reduce_store<6, ADM_THREADS / 64>(acc, red, partial + tile * 6);
+    block_reduce_store_lds<6, ADM_THREADS>(acc, red, partial + tile * 6);    // red aliases vbuf: 12 KB of its 36 KB
 }
 
 // ---------------------------------------------------------------- motion
