@@ -802,7 +802,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
     const bool vcol_avx = ORDER == ORDER_AVX && avx_vcol_ok(xc, w);
     int roff[MO_RPT + 4];                                             // one plane holds < 2^31 floats (engine limit)
 #pragma unroll
-    for (int k = 0; k < MO_RPT + 4; ++k) roff[k] = mirror_idx(vy0 - 2 + k, h) * row_stride;
+    for (int k = 0; k < MO_RPT + 4; ++k) roff[k] = mirror_idx(vy0 - 2 + k, h) * row_stride * 4;      // byte offsets, wave-uniform (SGPRs)
     // horizontal-pass identity
     const int hr = tid >> 3, ox0 = (tid & 7) * MO_OPT;
     const int gy = y0 + hr;
@@ -821,10 +821,11 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
 #pragma unroll
         for (int j = 0; j < MO_OPT; ++j) prev[j] = 0.0f;
     }
+    const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
     {
-        const float *p = ref + (size_t)f * frame_stride + xc;
+        const auto b = frame_rsrc(ref + (size_t)f * frame_stride, frame_bytes);
 #pragma unroll
-        for (int k = 0; k < MO_RPT + 4; ++k) in[k] = p[roff[k]];
+        for (int k = 0; k < MO_RPT + 4; ++k) in[k] = buf_load(b, xc * 4, roff[k]);
     }
     int buf = 0;
     for (; f < f_end; ++f, buf ^= 1) {
@@ -836,9 +837,9 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
             vb[(wv * MO_RPT + i) * MO_VP + lane] = taps_sel<5, true, ORDER>(in + i, 1, vcol_avx && avx_row_ok(vy0 + i, h, 2));
         __syncthreads();
         if (f + 1 < f_end) {
-            const float *p = ref + (size_t)(f + 1) * frame_stride + xc;
+            const auto b = frame_rsrc(ref + (size_t)(f + 1) * frame_stride, frame_bytes);
 #pragma unroll
-            for (int k = 0; k < MO_RPT + 4; ++k) in[k] = p[roff[k]];
+            for (int k = 0; k < MO_RPT + 4; ++k) in[k] = buf_load(b, xc * 4, roff[k]);
         }
         float win[MO_OPT + 4];
         {
