@@ -6,7 +6,7 @@
 
 Workload (BASELINE.json configs[1]): synthetic 1920x1080 yuv420p 8-bit ref/dis pair, luma resident in
 HBM as fp32 (what a read_frame callback delivers) before the timed region starts.  A step = one batch of
-FRAMES_PER_STEP consecutive frames through the whole hot path; default 20 steps x 30 frames = 600 frames.
+FRAMES_PER_STEP consecutive frames through the whole hot path; default 50 steps x 30 frames = 1500 frames.
 Multi-GPU: contiguous frame ranges per rank with a one-frame motion halo (weak scaling: every rank gets
 steps x 30 frames), per-frame atom rows gathered to rank 0 over RCCL, SVR fusion for all frames on rank 0 -
 all inside the timed region.
@@ -103,7 +103,7 @@ def cpu_baseline(ref, dis, frames_per_thread=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",

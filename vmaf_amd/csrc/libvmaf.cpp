@@ -12,6 +12,7 @@
 #include <cstring>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -433,7 +434,16 @@ int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int
 {
     try {
         if (!model_path || !atoms || !vmaf_out || nframes <= 0) throw VmafException("bad argument");
-        const vmaf_amd::VmafModel model = vmaf_amd::load_vmaf_model(model_path);
+        // repeated calls with one model (a rank fusing batch after batch) parse the two model files once
+        static std::mutex mu;
+        static std::map<std::string, vmaf_amd::VmafModel> cache;
+        vmaf_amd::VmafModel model;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = cache.find(model_path);
+            if (it == cache.end()) it = cache.emplace(model_path, vmaf_amd::load_vmaf_model(model_path)).first;
+            model = it->second;
+        }
         std::vector<double> a(atoms, atoms + (size_t)nframes * kAtoms), vmaf;
         std::map<std::string, std::vector<double>> feats;
         fuse(model, a, (size_t)nframes, disable_clip != 0, enable_transform != 0, device, vmaf, feats);
