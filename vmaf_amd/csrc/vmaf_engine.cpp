@@ -267,15 +267,15 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     int q = 0;
     for (int sc = 0; sc < 4; ++sc)
         for (int c = 0; c < 2; ++c)
-            tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c, 0, 0 };
+            tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c };
     for (int sc = 0; sc < 4; ++sc)
-        for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c, 0, 0 };
-    tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0, 0, 0 };
-    tab.d[q++] = { e->part_off_psnr, e->m_psnr ? e->tiles_psnr : 0, 1, 0, 0, 0 };
-    for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c, 0, 0 };
+        for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c };
+    tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0 };
+    tab.d[q++] = { e->part_off_psnr, e->m_psnr ? e->tiles_psnr : 0, 1, 0 };
+    for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c };
     for (int i = 0; i < 5; ++i)
-        for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ms[i], e->m_ms ? e->tiles_ms[i] : 0, 4, c, 0, 0 };
-    for (int c = 0; c < 2; ++c) tab.d[q++] = { e->part_off_ansnr, e->m_ansnr ? e->tiles_ansnr : 0, 2, c, 0, 0 };
+        for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ms[i], e->m_ms ? e->tiles_ms[i] : 0, 4, c };
+    for (int c = 0; c < 2; ++c) tab.d[q++] = { e->part_off_ansnr, e->m_ansnr ? e->tiles_ansnr : 0, 2, c };
     HIP_TRY(vk_launch_reduce(e->partials, &tab, nframes, e->sums_dev, e->s_main));
     HIP_TRY(hipMemcpyAsync(e->sums_host[slot], e->sums_dev, sizeof(double) * VK_NSUMS * nframes, hipMemcpyDeviceToHost, e->s_main));
     if (e->timed) HIP_TRY(hipEventRecord(e->ev_t1[slot], e->s_main));

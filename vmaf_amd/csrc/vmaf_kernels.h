@@ -21,8 +21,6 @@ typedef struct {
     int ntiles;      // blocks per frame in the producing kernel
     int k;           // doubles per block
     int comp;        // which of the k this sum takes
-    size_t offset2;  // optional second section with the same k; ntiles2 = 0 when unused
-    int ntiles2;
 } vk_reduce_desc;
 
 typedef struct { vk_reduce_desc d[VK_NSUMS]; } vk_reduce_table;

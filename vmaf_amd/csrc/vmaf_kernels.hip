@@ -1121,8 +1121,6 @@ __global__ __launch_bounds__(256) void reduce_kernel(const double *__restrict__ 
     const double *p = partial + d.offset + (size_t)f * d.ntiles * d.k + d.comp;
     double acc[1] = { 0.0 };
     for (int t = threadIdx.x; t < d.ntiles; t += 256) acc[0] += p[(size_t)t * d.k];
-    const double *p2 = partial + d.offset2 + (size_t)f * d.ntiles2 * d.k + d.comp;
-    for (int t = threadIdx.x; t < d.ntiles2; t += 256) acc[0] += p2[(size_t)t * d.k];
     block_reduce_store<1, 4>(acc, red, sums + (size_t)f * VK_NSUMS + blockIdx.x);
 }
 
