@@ -54,6 +54,8 @@ def lib():
         L.oracle_adm_csf_rfactors.argtypes = [_fp]
         L.oracle_log2f_approx.argtypes = [C.c_float]
         L.oracle_log2f_approx.restype = C.c_float
+        L.oracle_adm_dwt2_ll.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp]
+        L.oracle_adm_dwt2_ll.restype = None
         L.oracle_psnr.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         L.oracle_psnr.restype = C.c_double
         L.oracle_ssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, _dp]
@@ -367,3 +369,28 @@ def ref_ansnr(ref_raw, dis_raw, bits=8):
     a, b = C.c_double(), C.c_double()
     assert R.compute_ansnr(_ptr(r), _ptr(d), w, h, sb, sb, C.byref(a), C.byref(b), *_peak(bits)) == 0
     return a.value, b.value
+
+
+# ---------------------------------------------------------------- stage-level planes (tests of the GPU intermediates)
+def vif_pyramid(plane_off, order=ORDER_SCALAR):
+    """The planes compute_vif works on at scales 1..3 (vif.c:157-186): blur with the scale's own filter, then
+    vif_dec2 (vif_tools.c:146-159: dst[i][j] = src[2i][2j], i < h/2, j < w/2).  plane_off: after the -128 offset."""
+    out, cur = [], _f32(plane_off)
+    for s in (1, 2, 3):
+        h, w = cur.shape
+        blur = conv_sep(vif_filter(s), cur, order)
+        cur = np.ascontiguousarray(blur[0:2 * (h // 2):2, 0:2 * (w // 2):2])
+        out.append(cur)
+    return out
+
+
+def adm_ll_pyramid(plane_off):
+    """The LL bands compute_adm hands from scale to scale (adm.c:241-247), levels 0..2."""
+    out, cur = [], _f32(plane_off)
+    for _ in range(3):
+        h, w = cur.shape
+        ll = np.zeros(((h + 1) // 2, (w + 1) // 2), np.float32)
+        lib().oracle_adm_dwt2_ll(_ptr(cur), w, h, w, _ptr(ll))
+        out.append(ll)
+        cur = ll
+    return out

@@ -310,6 +310,17 @@ static void dwt2(const float *src, int w, int h, int stride, bands_t out, int os
     free(lo);
 }
 
+/* Stage-level hook for tests: the approximation band of one DWT level, i.e. the plane compute_adm hands to the next
+ * scale (adm.c:241-247).  out: ((w+1)/2) x ((h+1)/2), dense. */
+void oracle_adm_dwt2_ll(const float *src, int w, int h, int stride, float *out)
+{
+    const int w2 = (w + 1) / 2, h2 = (h + 1) / 2;
+    float *scratch = (float *)malloc(sizeof(float) * 3 * w2 * h2);
+    bands_t b = { out, scratch, scratch + w2 * h2, scratch + 2 * w2 * h2 };
+    dwt2(src, w, h, stride, b, w2);
+    free(scratch);
+}
+
 static inline float div_rcp(float n, float d, int exact_rcp)
 {
 #ifdef ORACLE_HAVE_RCPSS

@@ -60,6 +60,9 @@ void oracle_adm_csf_rfactors(float out[8]);
 /* vif_tools.c:46-75 */
 float oracle_log2f_approx(float x);
 
+/* stage-level hook: LL band of one db2 DWT level (adm_tools.c:293-393), ((w+1)/2) x ((h+1)/2) dense */
+void oracle_adm_dwt2_ll(const float *src, int w, int h, int stride, float *out);
+
 /* ---- optional per-frame metrics (oracle/iqa_oracle.c): psnr.c, ssim.c, ms_ssim.c, iqa/ ---- */
 double oracle_psnr(const float *ref, const float *dis, int w, int h, int stride, double peak, double psnr_max);
 int oracle_ssim_scale(int w, int h);

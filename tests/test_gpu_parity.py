@@ -321,3 +321,23 @@ def test_ansnr_matches_oracle(bits, w, h):
         e.extract(ref[:1], ref[:1])
         want = oracle.ansnr(ref[0], ref[0], bits)        # identical planes still differ after the two different filters
         assert abs(e.metrics[0, 3] - want[0]) < 1e-4 and abs(e.metrics[0, 4] - want[1]) < 1e-4
+
+
+@pytest.mark.parametrize("order", ["avx", "scalar"])
+@pytest.mark.parametrize("w,h", [(576, 324), (577, 325), (200, 66), (1920, 1080)])
+def test_intermediate_planes_are_bit_exact(w, h, order):
+    """Stage level (the reference's *_OPT_DEBUG_DUMP counterpart): the planes that do touch HBM - the VIF pyramid
+    (blur + vif_dec2, vif.c:157-186) and the ADM LL bands (adm.c:241-247) - equal the oracle's BIT FOR BIT in both
+    summation orders, border frame included.  (The oracle's convolution is bit-exact against the compiled reference.)"""
+    ref, dis = _clip(w, h, 2, seed=w * 3 + h)
+    with vmaf_amd.Engine(w, h, max_batch=2, order=order) as e:
+        e.extract(ref, dis)
+        for f in (0, 1):
+            for name, plane in (("ref", ref[f]), ("dis", dis[f])):
+                off = plane + np.float32(-128)
+                for lvl, want in enumerate(oracle.vif_pyramid(off, ORDERS[order]), start=1):
+                    got = e.debug_plane("vif_" + name, lvl, f)
+                    assert got.shape == want.shape and np.array_equal(got, want), (name, lvl, f)
+                for lvl, want in enumerate(oracle.adm_ll_pyramid(off), start=1):
+                    got = e.debug_plane("adm_" + name, lvl, f)
+                    assert got.shape == want.shape and np.array_equal(got, want), (name, lvl, f)

@@ -63,6 +63,7 @@ def load_library():
     L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_engine_sync_oldest.argtypes = [vp]
+    L.vmaf_hip_engine_debug_read_plane.argtypes = [vp, i, i, i, _fp, sz, C.POINTER(i), C.POINTER(i)]
     L.vmaf_hip_host_alloc.argtypes = [sz]
     L.vmaf_hip_host_alloc.restype = vp
     L.vmaf_hip_host_free.argtypes = [vp]
@@ -215,6 +216,15 @@ class Engine:
     def sync(self):
         if self.L.vmaf_hip_engine_sync(self._h):
             raise VmafHipError(_err(self.L))
+
+    def debug_plane(self, kind, level, frame=0):
+        """Stage-level test hook: kind 'vif_ref' | 'vif_dis' | 'adm_ref' | 'adm_dis', level 1..3 -> float32 [h,w]."""
+        k = {"vif_ref": 0, "vif_dis": 1, "adm_ref": 2, "adm_dis": 3}[kind]
+        buf = np.zeros(self.w * self.h, np.float32)
+        w, h = C.c_int(), C.c_int()
+        if self.L.vmaf_hip_engine_debug_read_plane(self._h, k, level, frame, buf.ctypes.data_as(_fp), buf.size, C.byref(w), C.byref(h)):
+            raise VmafHipError(_err(self.L))
+        return buf[:w.value * h.value].reshape(h.value, w.value).copy()
 
     def sync_oldest(self):
         """Finish the oldest of the (at most two) asynchronous extract calls in flight."""

@@ -538,6 +538,24 @@ int vmaf_hip_engine_sync(vmaf_hip_engine *e)
     return 0;
 }
 
+int vmaf_hip_engine_debug_read_plane(vmaf_hip_engine *e, int kind, int level, int frame, float *out, size_t out_floats,
+                                     int *width, int *height)
+{
+    if (!e || !out) return fail("null argument");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
+    if (kind < 0 || kind > 3 || level < 1 || level > 3) return fail("kind %d / level %d outside 0..3 / 1..3", kind, level);
+    if (frame < 0 || frame >= e->max_batch) return fail("frame %d outside the batch", frame);
+    const bool vif = kind < 2;
+    const int w = vif ? e->vw[level] : e->aw[level], h = vif ? e->vh[level] : e->ah[level];
+    const float *src = (kind == 0 ? e->vif_ref : kind == 1 ? e->vif_dis : kind == 2 ? e->adm_ref : e->adm_dis)[level];
+    if ((size_t)w * h > out_floats) return fail("plane %dx%d does not fit %zu floats", w, h, out_floats);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(out, src + (size_t)frame * w * h, sizeof(float) * w * h, hipMemcpyDeviceToHost));
+    if (width) *width = w;
+    if (height) *height = h;
+    return 0;
+}
+
 int vmaf_hip_engine_sync_oldest(vmaf_hip_engine *e)
 {
     if (!e) return fail("null engine");
