@@ -297,7 +297,8 @@ __device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float
 // horizontal pass 32 rows * (48/6) strips = 256 items, so all four waves work in both phases; 48 divides
 // every level of the 1080p / 4K pyramids (1920, 960, 480, 240).
 constexpr int VIF_TW = 48, VIF_TH = 32, VIF_THREADS = 256, VIF_SV = 8, VIF_SH = 6;
-constexpr int VIF_BLOCKS_PER_CU = 4;                          // 32 KB LDS and <= 128 VGPRs per workgroup
+constexpr int VIF_WAVES_PER_SIMD = 4;                         // HIP: 2nd __launch_bounds__ argument = min waves per SIMD;
+                                                              // 32 KB LDS and <= 128 VGPRs per workgroup -> 4 workgroups per CU
 
 template <int FW> struct VifGeom {
     static constexpr int R = FW / 2;
@@ -387,7 +388,7 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
 // picks its order exactly as convolution_f32_avx_s_1d does (convolution_avx.c:806-836); both write
 // partial[frame][tile] and the decimated planes of their own tiles.
 template <int FW, bool OFFSET, int ORDER, bool BORDER>
-__global__ __launch_bounds__(VIF_THREADS, VIF_BLOCKS_PER_CU) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+__global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                                size_t frame_stride, int row_stride, int w, int h,
                                                                double *__restrict__ partial,
                                                                float *__restrict__ oref, float *__restrict__ odis,
