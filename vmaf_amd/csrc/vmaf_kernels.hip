@@ -991,16 +991,33 @@ __global__ __launch_bounds__(256) void lpf_decimate_kernel(const float *__restri
 // ssim_tools.h: g_gaussian_window_h == g_gaussian_window_v
 constexpr float kSsimWin[11] = { 0.001028f, 0.007599f, 0.036001f, 0.109361f, 0.213006f, 0.266012f, 0.213006f, 0.109361f,
                                  0.036001f, 0.007599f, 0.001028f };
-constexpr int SS_TW = 32, SS_TH = 16, SS_IW = SS_TW + 10, SS_IH = SS_TH + 10, SS_IP = SS_IW + 1;
+constexpr int SS_TW = 64, SS_TH = 16, SS_IW = SS_TW + 10, SS_IH = SS_TH + 10, SS_IP = SS_IW + 2;   // staged 26 x 74 (pitch 76)
+constexpr int SS_SEG = 8;                                      // outputs per thread in the horizontal pass
+static_assert(SS_IH * (SS_TW / SS_SEG) <= 256 && SS_TW * (SS_TH / 4) == 256, "thread maps of ssim_stat_kernel");
+
+// 11-tap window sum of the reference: float products, double running sum, float result (iqa/convolve.c:113-143)
+template <int NOUT> __device__ __forceinline__ void ssim_taps(const float *win, float *out)
+{
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) sum += (double)(win[o + k] * kSsimWin[k]);
+        out[o] = (float)sum;
+    }
+}
 
 // _iqa_ssim with default arguments (iqa/ssim_tools.c:92-243) on dense planes [frame][h][w]: "valid" 11-tap
 // separable Gaussian of {ref, cmp, ref^2, cmp^2, ref*cmp} (horizontal pass first, iqa/convolve.c:113-143), sigma,
 // l / c / s per pixel in double, four sums per workgroup: sum(l*c*s), sum(l), sum(c), sum(s).
+// Horizontal pass: thread = (row, 8 outputs), the 18-sample windows of ref and cmp in registers, products formed
+// there; vertical pass: thread = (column, 4 outputs) with a 14-sample register window per quantity.
 __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
                                                         double *__restrict__ partial)
 {
-    __shared__ float pl[5][SS_IH * SS_IP];
-    __shared__ float hc[5][SS_IH * SS_TW];
+    __shared__ __attribute__((aligned(16))) float rt[SS_IH * SS_IP];
+    __shared__ __attribute__((aligned(16))) float ct[SS_IH * SS_IP];
+    __shared__ __attribute__((aligned(16))) float hc[5][SS_IH * SS_TW];
     __shared__ double red[16];
     const int tid = threadIdx.x;
     const int vw = w - 10, vh = h - 10;                              // valid output size
@@ -1009,50 +1026,65 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
     for (int idx = tid; idx < SS_IH * SS_IW; idx += 256) {
         const int ly = idx / SS_IW, lx = idx - ly * SS_IW;
         const size_t g = (size_t)min(y0 + ly, h - 1) * w + min(x0 + lx, w - 1);   // clamped reads feed masked outputs only
-        const float a = fr[g], b = fc[g];
-        const int o = ly * SS_IP + lx;
-        pl[0][o] = a; pl[1][o] = b; pl[2][o] = a * a; pl[3][o] = b * b; pl[4][o] = a * b;
+        rt[ly * SS_IP + lx] = fr[g];
+        ct[ly * SS_IP + lx] = fc[g];
     }
     __syncthreads();
-    for (int idx = tid; idx < 5 * SS_IH * SS_TW; idx += 256) {
-        const int q = idx / (SS_IH * SS_TW), rem = idx - q * (SS_IH * SS_TW);
-        const int ly = rem / SS_TW, lx = rem - ly * SS_TW;
-        const float *p = &pl[q][ly * SS_IP + lx];
-        double sum = 0.0;
+    if (tid < SS_IH * (SS_TW / SS_SEG)) {
+        const int row = tid / (SS_TW / SS_SEG), seg = tid - row * (SS_TW / SS_SEG);
+        float a[SS_SEG + 10], b[SS_SEG + 10], t[SS_SEG + 10], o[SS_SEG];
+        const float2 *pa = reinterpret_cast<const float2 *>(rt + row * SS_IP + seg * SS_SEG);
+        const float2 *pb = reinterpret_cast<const float2 *>(ct + row * SS_IP + seg * SS_SEG);
 #pragma unroll
-        for (int k = 0; k < 11; ++k) sum += (double)(p[k] * kSsimWin[k]);
-        hc[q][rem] = (float)sum;
+        for (int m = 0; m < (SS_SEG + 10) / 2; ++m) {
+            const float2 u = pa[m], v = pb[m];
+            a[2 * m] = u.x; a[2 * m + 1] = u.y; b[2 * m] = v.x; b[2 * m + 1] = v.y;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const float *src = q == 0 ? a : q == 1 ? b : t;
+            if (q >= 2) {
+#pragma unroll
+                for (int k = 0; k < SS_SEG + 10; ++k) t[k] = q == 2 ? a[k] * a[k] : q == 3 ? b[k] * b[k] : a[k] * b[k];
+            }
+            ssim_taps<SS_SEG>(src, o);
+            float4 *dst = reinterpret_cast<float4 *>(&hc[q][row * SS_TW + seg * SS_SEG]);
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
     }
     __syncthreads();
     const float K1 = 0.01f, K2 = 0.03f;
     const int L = 255;
     const float C1 = (K1 * L) * (K1 * L), C2 = (K2 * L) * (K2 * L);
     double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-    for (int it = 0; it < SS_TH * SS_TW / 256; ++it) {
-        const int ox = tid & 31, oy = (tid >> 5) + it * 8;
-        float m[5];
+    {
+        const int ox = tid & (SS_TW - 1), oy0 = (tid / SS_TW) * 4;
+        float m[5][4];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            double sum = 0.0;
+            float win[14];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) sum += (double)(hc[q][(oy + k) * SS_TW + ox] * kSsimWin[k]);
-            m[q] = (float)sum;
+            for (int k = 0; k < 14; ++k) win[k] = hc[q][(oy0 + k) * SS_TW + ox];
+            ssim_taps<4>(win, m[q]);
         }
-        if (x0 + ox < vw && y0 + oy < vh) {
-            const float ref_mu = m[0], cmp_mu = m[1];
-            float rss = m[2], css = m[3], sb = m[4];
-            rss -= ref_mu * ref_mu;
-            css -= cmp_mu * cmp_mu;
-            rss = (float)((0.0 > rss) ? 0.0 : rss);
-            css = (float)((0.0 > css) ? 0.0 : css);
-            sb -= ref_mu * cmp_mu;
-            const double srsc = sqrt((double)(rss * css));
-            const double l = (2.0 * ref_mu * cmp_mu + C1) / (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
-            const double c = (2.0 * srsc + C2) / (double)(rss + css + C2);
-            const double s = (sb + C2 / 2.0) / (srsc + C2 / 2.0);
-            acc[0] += l * c * s;
-            acc[1] += l; acc[2] += c; acc[3] += s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (x0 + ox < vw && y0 + oy0 + j < vh) {
+                const float ref_mu = m[0][j], cmp_mu = m[1][j];
+                float rss = m[2][j], css = m[3][j], sb = m[4][j];
+                rss -= ref_mu * ref_mu;
+                css -= cmp_mu * cmp_mu;
+                rss = (float)((0.0 > rss) ? 0.0 : rss);
+                css = (float)((0.0 > css) ? 0.0 : css);
+                sb -= ref_mu * cmp_mu;
+                const double srsc = sqrt((double)(rss * css));
+                const double l = (2.0 * ref_mu * cmp_mu + C1) / (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
+                const double c = (2.0 * srsc + C2) / (double)(rss + css + C2);
+                const double s_ = (sb + C2 / 2.0) / (srsc + C2 / 2.0);
+                acc[0] += l * c * s_;
+                acc[1] += l; acc[2] += c; acc[3] += s_;
+            }
         }
     }
     block_reduce_store<4, 4>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x) * 4);
