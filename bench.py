@@ -44,6 +44,7 @@ WORKLOADS = {"1080p": (1920, 1080, 8, 30), "4k10": (3840, 2160, 10, 8), "720p": 
 MODEL = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PATH_BYTES_PER_PX = 26.5        # algorithmic bytes of the whole path per luma pixel
+PATH_FLOP_PER_PX = 620.0       # algorithmic fp32 flops of the whole path per luma pixel
 VIF0_BYTES_PER_PX = 10.0        # dominant kernel: reads the fp32 ref and dis planes once (8 B/px) and writes the
                                 # two decimated planes of the next VIF scale (2 x 4 B / 4 px = 2 B/px)
 
@@ -218,7 +219,11 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": prof.get("traffic"), "algorithmic_bytes": int(VIF0_BYTES_PER_PX * W * H * B),
                     "launch_ms": round(kernel_ms, 4), "frames_per_launch": B,
-                    "path_achieved_gbs": round(PATH_BYTES_PER_PX * W * H * fps / world / 1e9, 1)}
+                    "path_achieved_gbs": round(PATH_BYTES_PER_PX * W * H * fps / world / 1e9, 1),
+                    # ~620 fp32 flop per pixel over the whole path; mul and add stay unfused by the parity
+                    # rule, so the VALU ceiling is half the FMA peak (157.3 / 2 TFLOP/s)
+                    "path_achieved_tflops": round(PATH_FLOP_PER_PX * W * H * fps / world / 1e12, 2),
+                    "fp32_unfused_peak_tflops": 78.6}
             if excl_ms:
                 roof["exclusive"] = {"launch_ms": round(excl_ms, 4), "achieved": round(VIF0_BYTES_PER_PX * W * H * B / (excl_ms * 1e-3) / 1e9, 1),
                                      "frac": round(VIF0_BYTES_PER_PX * W * H * B / (excl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
