@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
                     help="1080p = BASELINE.json configs[1], the headline workload (default); the others are for DESIGN.md's table")
+    ap.add_argument("--order", choices=["avx", "scalar", "fma"], default="avx",
+                    help="summation order of the convolutions: the reference's AVX order (default, bit-exact), its scalar order, "
+                         "or fused multiply-adds (fast mode, within tolerance but not bit-exact; not the headline workload)")
     ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
     args = ap.parse_args()
 
@@ -141,7 +144,7 @@ def main():
     t_ref, t_dis = torch.from_numpy(ref).to(dev), torch.from_numpy(dis).to(dev)
     torch.cuda.synchronize()
 
-    eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank)
+    eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order)
     if args.metrics:
         eng.L.vmaf_hip_engine_enable_metrics(eng._h, 1, 1, 1, 0)
     atoms = np.zeros((K, B, 20))
@@ -193,7 +196,7 @@ def main():
         prev_serial = os.environ.get("VMAF_HIP_SERIAL")
         os.environ["VMAF_HIP_SERIAL"] = "1"
         try:
-            with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank) as eng1:
+            with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order) as eng1:
                 eng1.extract_device(t_ref, t_dis, B, out=scratch)
                 eng1.arm_timing()
                 xs = []
@@ -207,6 +210,29 @@ def main():
                 del os.environ["VMAF_HIP_SERIAL"]
             else:
                 os.environ["VMAF_HIP_SERIAL"] = prev_serial
+    fast = None
+    if rank == 0 and world == 1 and args.order == "avx" and not args.metrics:
+        # beside the headline: the opt-in fused-multiply-add order (conv order 2, VMAF_HIP_FAST=1) on the same workload,
+        # same pipelined loop + fusion, outside the timed region; and how far its numbers are from the headline run's
+        with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order="fma") as engf:
+            fa = np.zeros((K, B, 20))
+            for i in range(args.warmup):
+                engf.extract_device(t_ref, t_dis, B, continue_sequence=i > 0, out=scratch)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for k in range(K):
+                engf.extract_device(t_ref, t_dis, B, continue_sequence=k > 0, out=fa[k], sync=False)
+                if k > 0:
+                    engf.sync_oldest()
+            engf.sync()
+            fv, ff = vmaf_amd.predict_from_atoms(fa.reshape(K * B, 20), MODEL, device=local_rank)
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - tf0
+        _, f0 = vmaf_amd.predict_from_atoms(flat, MODEL, device=local_rank)
+        fast = {"order": "fma (fused multiply-add taps; within tolerance, not bit-identical to the reference)",
+                "value": round(K * B / tf, 2), "unit": "frames/sec", "ms_per_step": round(1e3 * tf / K, 4),
+                "max_abs_feature_diff_vs_headline": float(np.abs(ff - f0).max()),
+                "max_abs_vmaf_diff_vs_headline": float(np.abs(fv - vmaf).max())}
     if rank == 0:
         frames = world * K * B
         fps = frames / elapsed
@@ -214,8 +240,8 @@ def main():
         roof = None
         if kernel_ms:
             achieved = VIF0_BYTES_PER_PX * W * H * B / (kernel_ms * 1e-3) / 1e9
-            prof = committed_profile(B)
-            roof = {"bound": "hbm", "kernel": "vif_stat_kernel<17> (VIF scale 0, fused; interior + border-frame launches)",
+            prof = committed_profile(B) if args.order == "avx" else {}     # the committed counters are of the default order
+            roof = {"bound": "hbm", "kernel": "vif_stat_avx_kernel<17> (VIF scale 0, fused; border-frame + interior tiles in one launch)" if args.order == "avx" else f"vif_stat_kernel<17> ({args.order} order)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": prof.get("traffic"), "algorithmic_bytes": int(VIF0_BYTES_PER_PX * W * H * B),
                     "launch_ms": round(kernel_ms, 4), "frames_per_launch": B,
@@ -243,6 +269,10 @@ def main():
                            "frames_per_step_per_gpu": B, "frames_total": frames,
                            "parallelism": f"frame-range x{world}, 1-frame motion halo" if world > 1 else "single GPU"},
                 "mean_vmaf": round(float(np.mean(vmaf)), 4), "roofline": roof}
+        if fast:
+            line["fast_mode"] = fast
+        if args.order != "avx":
+            line["config"]["conv_order"] = args.order
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ref, dis)
         print(json.dumps(line), flush=True)

@@ -152,6 +152,18 @@ def test_raw_and_fp32_callbacks_give_identical_logs(name, tmp_path):
     assert logs[0] == logs[1] and len(logs[0]) == len(case["frames"])
 
 
+def test_fast_mode_env_keeps_the_cli_inside_the_tolerances(tmp_path):
+    """VMAF_HIP_FAST=1: compute_vmaf runs the fused order (conv order 2).  Same schema, values within 1e-4 / 1e-3 of what
+    the reference's vmafossexec printed for the same files; --disable-avx still selects the reference's scalar order."""
+    case = EXEC["default"]
+    rp, dp, w, h = _files(case, tmp_path)
+    log = str(tmp_path / "fast.xml")
+    cmd = [OURS, case["fmt"], str(w), str(h), rp, dp, os.path.join(ROOT, case["model"]), "--log", log] + case["args"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, VMAF_HIP_FAST="1"))
+    assert p.returncode == 0, p.stderr + p.stdout
+    _check_against_golden(p.stdout, open(log).read(), case)
+
+
 FEATURE_TOOL = json.load(open(os.path.join(GOLD, "feature_tool.json")))
 
 

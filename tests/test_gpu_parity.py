@@ -70,6 +70,37 @@ def test_noisy_image_where_the_two_orders_diverge(golden_dir):
     assert abs(got["avx"] - 65.415667) < 1e-4 and abs(got["scalar"] - 65.412008) < 1e-4
 
 
+@pytest.mark.parametrize("w,h,frames,kw", [(64, 48, 5, {}), (577, 325, 3, {}), (576, 324, 4, dict(cuts=(2,))), (96, 64, 3, dict(dis_noise=25)),
+                                           (1920, 1080, 2, {}), (320, 180, 3, dict(bits=10))])
+def test_fused_order_stays_inside_the_tolerances(w, h, frames, kw, model_path):
+    """Conv order 2 ("fma", opt-in fast mode; not one of the reference's orders): fused multiply-adds in the VIF / motion /
+    db2 taps.  Not bit-identical, so it is held to the north-star tolerances against the oracle in the reference's default
+    (AVX) order: features 1e-4 absolute, per-frame and mean VMAF 1e-3; the raw sums to 1e-4 relative."""
+    bits = kw.pop("bits", 8)
+    ref, dis = _clip(w, h, frames, bits=bits, seed=w + h, **kw)
+    want = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX)
+    with vmaf_amd.Engine(w, h, max_batch=4, order="fma") as e:
+        got = e.extract(ref, dis)
+    assert not np.array_equal(got, want) or w * h < 64 * 64            # it really is a different rounding
+    for k, name in enumerate(vmaf_amd.ATOM_NAMES):
+        assert np.all(np.abs(got[:, k] - want[:, k]) <= 1e-4 * np.maximum(1.0, np.abs(want[:, k]))), name
+    fg, fw = _feats(got), _feats(want)
+    for k in fw:
+        assert np.all(np.abs(fg[k] - fw[k]) <= FEATURE_TOL), f"feature {k}: {fg[k]} vs {fw[k]}"
+    vg, vw = vmaf_amd.predict_from_atoms(got, model_path)[0], vmaf_amd.predict_from_atoms(want, model_path)[0]
+    assert np.all(np.abs(vg - vw) < 1e-3) and abs(vg.mean() - vw.mean()) < 1e-3
+
+
+def test_fused_order_on_the_noisy_image(golden_dir):
+    """On tests/golden/images/100007 the reference's own two orders are 3.7e-3 VMAF apart; the fused order has to stay
+    within 1e-3 of the default (AVX) one - it lands at ~1e-4."""
+    ref = np.fromfile(os.path.join(golden_dir, "images", "100007.yuv"), np.uint8)[:481 * 321].reshape(1, 321, 481).astype(np.float32)
+    dis = np.fromfile(os.path.join(golden_dir, "images", "100007_noisy.yuv"), np.uint8)[:481 * 321].reshape(1, 321, 481).astype(np.float32)
+    with vmaf_amd.Engine(481, 321, order="fma") as e:
+        a = e.extract(ref, dis)
+    assert abs(vmaf_amd.predict_from_atoms(a)[0][0] - 65.415667) < 1e-3
+
+
 def test_ten_bit_input():
     ref, dis = _clip(320, 180, 3, bits=10, seed=5)
     assert np.any(ref != np.round(ref))            # quarter steps really present

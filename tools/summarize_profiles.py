@@ -85,8 +85,8 @@ def main():
                 d = dur.get(k)
                 frac = round(row[0] * 2 / (1024 * d * 1e-9 * 2.4e9), 3) if d else ""
                 wr.writerow([k, round(d / 1e3, 1) if d else ""] + [int(x) for x in row] + [frac])
-    # the dominant kernel = VIF scale 0 = the two launches of vif_stat_kernel<17,...> (interior tiles, border-frame tiles)
-    dom = [r for r in rows if r["kernel"].startswith("vif_stat_kernel<17")]
+    # the dominant kernel = VIF scale 0 = vif_stat_avx_kernel<17, true> (border-frame + interior tiles in one launch)
+    dom = [r for r in rows if r["kernel"].startswith("vif_stat_avx_kernel<17")]
     if dom:
         valu = sum(cnt["SQ_INSTS_VALU"].get(r["kernel"], (0.0, 0))[0] for r in dom)
         json.dump({"source": f"profiles/{tag}_hbm_traffic.csv, profiles/{tag}_valu_counters.csv",

@@ -101,7 +101,7 @@ class Engine:
         self._keep = None
         self._metrics_on = False
         self.metrics = np.zeros((0, N_METRICS))      # of the frames of the last extract / extract_raw call
-        if self.L.vmaf_hip_engine_set_conv_order(h, {"avx": 1, "scalar": 0}[order]):
+        if self.L.vmaf_hip_engine_set_conv_order(h, {"avx": 1, "scalar": 0, "fma": 2}[order]):
             raise VmafHipError(_err(self.L))
 
     def close(self):

@@ -68,7 +68,7 @@ struct vmaf_hip_engine {
     hipEvent_t ev_t0[kDepth] = {}, ev_t1[kDepth] = {}, ev_k0[kDepth] = {}, ev_k1[kDepth] = {}, ev_done[kDepth] = {};
     bool timed = false;
     bool serial = false;
-    int order = 1;                 // convolution tap order: 1 = reference AVX path (default), 0 = scalar path
+    int order = 1;                 // convolution tap order: 1 = reference AVX path (default), 0 = scalar path, 2 = fused (fast, not bit-exact)
 
     int vw[4], vh[4];              // VIF plane size per scale
     int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
@@ -245,7 +245,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
         const int bw = e->aw[sc + 1], bh = e->ah[sc + 1];
         const size_t lfs = (size_t)bw * bh;
         float *lr = sc < 3 ? e->adm_ref[sc + 1] : nullptr, *ld = sc < 3 ? e->adm_dis[sc + 1] : nullptr;
-        HIP_TRY(vk_launch_adm_scale(sc, cr, cd, cfs, crs, e->aw[sc], e->ah[sc], lr, ld, lfs, bw, e->rfac[2 * sc], e->rfac[2 * sc + 1],
+        HIP_TRY(vk_launch_adm_scale(sc, e->order, cr, cd, cfs, crs, e->aw[sc], e->ah[sc], lr, ld, lfs, bw, e->rfac[2 * sc], e->rfac[2 * sc + 1],
                                     e->win[sc][0], e->win[sc][1], e->win[sc][2], e->win[sc][3], nframes,
                                     e->partials + e->part_off_adm[sc], e->s_adm));
         cr = lr; cd = ld; cfs = lfs; crs = bw;
@@ -443,7 +443,7 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
 int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order)
 {
     if (!e) return fail("null engine");
-    if (order != 0 && order != 1) return fail("conv order %d is neither 0 (scalar) nor 1 (avx)", order);
+    if (order < 0 || order > 2) return fail("conv order %d is none of 0 (scalar), 1 (avx), 2 (fused multiply-add)", order);
     e->order = order;
     return 0;
 }

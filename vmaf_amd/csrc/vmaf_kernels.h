@@ -38,7 +38,7 @@ int vk_motion_tiles(int w, int h);
 hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s);
-hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+hipError_t vk_launch_adm_scale(int scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
                                double *partial, hipStream_t s);

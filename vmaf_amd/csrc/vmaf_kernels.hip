@@ -9,17 +9,19 @@
 //   ORDER_SCALAR taps accumulated left to right everywhere (vif_tools.c:292-328, convolution.c:26-76)
 // ADM has a single order in the reference (adm_tools.c:308-389).  Per-pixel values are therefore
 // bit-identical to the reference in the same mode; only the final plane sums differ (fp64 tree here,
-// fp32 row-then-total there).  In ORDER_AVX the fused VIF kernel computes the pure vector order and leaves
-// the thin frame of pixels that the reference computes (partly) with the scalar order to vif_border_kernel.
+// fp32 row-then-total there).
+//   ORDER_FMA    opt-in fast mode, not a reference order: sequential taps with fused multiply-adds
+//                (VIF, motion and ADM's db2 taps); within the parity tolerances, not bit-identical.
 //
 // Kernels (one launch covers a whole batch of frames: blockIdx.z = frame):
-//   vif_stat_kernel<FW>   fused: tile+halo of ref/dis -> LDS, vertical pass of {r,d,r^2,d^2,rd},
-//                         horizontal pass, per-pixel VIF statistic, block-reduced num/den; from the same tile
-//                         the next scale's input (blur with the next filter at even samples only)
-//   vif_border_kernel<FW> ORDER_AVX only: the border frame (top/bottom R rows, left R / right ~8 columns)
-//   adm_scale_kernel      fused: db2 DWT (ref+dis) in LDS, decouple, CSF, 3x3 masking threshold,
-//                         masked cube sums over the centre window, LL bands to HBM
-//   motion_kernel         5-tap blur of frame f and f-1 (or carried blurred plane), SAD
+//   vif_stat_kernel<FW>      fused: tile+halo of ref/dis -> LDS, vertical pass of {r,d,r^2,d^2,rd},
+//                            horizontal pass, per-pixel VIF statistic, block-reduced num/den; from the same tile
+//                            the next scale's input (blur with the next filter at even samples only)
+//   vif_stat_avx_kernel<FW>  the same for ORDER_AVX: border-frame tiles (per-sample order) and interior tiles
+//                            (pure vector order) in one launch
+//   adm_scale_kernel         fused: db2 DWT (ref+dis), decouple, CSF, 3x3 masking threshold,
+//                            masked cube sums over the centre window, LL bands to HBM
+//   motion_kernel            5-tap blur of frame f and f-1 (or carried blurred plane), SAD
 //   reduce_kernel         deterministic fp64 reduction of the per-block partials
 //   svm_rbf_kernel        batched nu-SVR RBF prediction
 #include <hip/hip_runtime.h>
@@ -51,7 +53,7 @@ template <int FW> __device__ __forceinline__ constexpr float vif_tap(int k)
 // MOTION selects FILTER_5_s (motion_tools.h), which differs from VIF's 5-tap table in the 8th digit
 template <int FW, bool MOTION> __device__ __forceinline__ constexpr float ftap(int k) { return MOTION ? kMotion5[k] : vif_tap<FW>(k); }
 
-constexpr int ORDER_SCALAR = 0, ORDER_AVX = 1;
+constexpr int ORDER_SCALAR = 0, ORDER_AVX = 1, ORDER_FMA = 2;
 
 // One output sample from p[0], p[st], .., p[(FW-1)*st], taps accumulated left to right.  The reference starts
 // from 0.0f; starting from the first product gives the same bits (0.0f + x == x) except for the sign of a
@@ -61,6 +63,17 @@ template <int FW, bool MOTION> __device__ __forceinline__ float taps_seq_at(cons
     float acc = ftap<FW, MOTION>(0) * p[0];
 #pragma unroll
     for (int k = 1; k < FW; ++k) acc = acc + ftap<FW, MOTION>(k) * p[k * st];
+    return acc;
+}
+
+// ORDER_FMA, the opt-in fast mode: the sequential order with every multiply-add fused (one rounding per tap instead of
+// two).  NOT one of the reference's two orders: samples differ from them in the last bits (features by ~1e-6, inside the
+// 1e-4 parity tolerance but not bit-identical), in exchange for half the VALU instructions of a convolution.
+template <int FW, bool MOTION> __device__ __forceinline__ float taps_fma_at(const float *p, int st)
+{
+    float acc = ftap<FW, MOTION>(0) * p[0];
+#pragma unroll
+    for (int k = 1; k < FW; ++k) acc = __builtin_fmaf(ftap<FW, MOTION>(k), p[k * st], acc);
     return acc;
 }
 
@@ -93,6 +106,7 @@ template <int FW, bool MOTION> __device__ __forceinline__ float taps_avx_at(cons
 template <int FW, bool MOTION, int ORDER> __device__ __forceinline__ float taps_sel(const float *p, int st, bool avx)
 {
     if (ORDER == ORDER_SCALAR) return taps_seq_at<FW, MOTION>(p, st);
+    if (ORDER == ORDER_FMA) return taps_fma_at<FW, MOTION>(p, st);
     float ra = 0.0f, rs = 0.0f;
     if (__any(avx)) ra = taps_avx_at<FW, MOTION>(p, st);
     if (__any(!avx)) rs = taps_seq_at<FW, MOTION>(p, st);
@@ -120,12 +134,12 @@ __device__ __forceinline__ int mirror_idx(int i, int n)
 // Tiles are numbered row-major; this bijection gives the blocks of one XCD a contiguous run of tiles, so the
 // halo rows/columns that neighbouring tiles have in common are fetched into that L2 once instead of once per
 // XCD.  Speed only - any placement is correct.  (grid.x = number of tiles, grid.z = frame)
-__device__ __forceinline__ int xcd_tile_index()
+__device__ __forceinline__ int xcd_tile_index(int b, int nt)
 {
-    const int b = blockIdx.x, nt = gridDim.x;
     const int q = nt >> 3, r = nt & 7, xcd = b & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
+__device__ __forceinline__ int xcd_tile_index() { return xcd_tile_index(blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------- tile staging
 // Stage an IH x IW window (IW % 4 == 0) of one or two planes, whose top-left corner is image pixel
@@ -330,7 +344,7 @@ __device__ __forceinline__ void taps_window(const float *v, float *out)
 {
 #pragma unroll
     for (int o = 0; o < NOUT; ++o)
-        out[o] = (ORDER == ORDER_SCALAR) ? taps_seq_at<FW, false>(v + o, 1) : taps_avx_at<FW, false>(v + o, 1);
+        out[o] = (ORDER == ORDER_SCALAR) ? taps_seq_at<FW, false>(v + o, 1) : (ORDER == ORDER_FMA) ? taps_fma_at<FW, false>(v + o, 1) : taps_avx_at<FW, false>(v + o, 1);
 }
 
 // Same with the order chosen per output (bit o of avx_mask): the tiles on the border frame of ORDER_AVX
@@ -383,41 +397,26 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
 // three filtered moments, vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.
 // From the same staged tile it also produces the next scale's input (vif.c:157-186): blur with the NEXT
 // scale's filter, evaluated at even rows/columns only, so ref/dis are read from HBM once per scale.
-// ORDER_AVX comes as two launches over disjoint tile sets: BORDER = false covers the tiles whose every sample is
-// in the vector order (it leaves the others at once), BORDER = true the border-frame tiles, where every sample
-// picks its order exactly as convolution_f32_avx_s_1d does (convolution_avx.c:806-836); both write
-// partial[frame][tile] and the decimated planes of their own tiles.
+// ORDER_AVX has two tile sets: BORDER = false for the tiles whose every sample is in the vector order, BORDER = true
+// for the border-frame tiles, where every sample picks its order exactly as convolution_f32_avx_s_1d does
+// (convolution_avx.c:806-836); both write partial[frame][tile] and the decimated planes of their own tiles.
+// One workgroup runs vif_tile once, for the tile its kernel (below) picks.
 template <int FW, bool OFFSET, int ORDER, bool BORDER>
-__global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
-                                                               size_t frame_stride, int row_stride, int w, int h,
-                                                               double *__restrict__ partial,
-                                                               float *__restrict__ oref, float *__restrict__ odis,
-                                                               size_t out_frame_stride, int out_row_stride)
+__device__ __forceinline__ void vif_tile(float *smem, int tile_id, const float *__restrict__ ref, const float *__restrict__ dis,
+                                         size_t frame_stride, int row_stride, int w, int h,
+                                         double *__restrict__ partial,
+                                         float *__restrict__ oref, float *__restrict__ odis,
+                                         size_t out_frame_stride, int out_row_stride)
 {
     using G = VifGeom<FW>;
     constexpr int R = G::R, IW = G::IW, IH = G::IH, VS = G::VS;
     constexpr int DFW = G::DFW, RD = G::RD, DVW = G::DVW;
-    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS + 16 + G::D_FLOATS];
     float *in_r = smem, *in_d = smem + IH * IW;
     float *dv_s = smem + G::SMEM_FLOATS + 16;                 // decimation: vertical results, [2][TH/2][DVW]
     double *red = reinterpret_cast<double *>(smem);           // reused after the last LDS read
 
     const int tid = threadIdx.x;
     const int ntx = (w + VIF_TW - 1) / VIF_TW;
-    int tile_id;
-    if (ORDER == ORDER_AVX) {
-        const BorderGeom bg = border_geom(w, h, R, VIF_TW, VIF_TH);
-        if (BORDER) {
-            int tx, ty;
-            border_tile_at(bg, blockIdx.x, tx, ty);
-            tile_id = ty * ntx + tx;
-        } else {                                              // the interior tiles form the rectangle [1, tx_r) x [1, ty_b)
-            const int i = xcd_tile_index(), iw = bg.tx_r - 1;
-            tile_id = (1 + i / iw) * ntx + 1 + i % iw;
-        }
-    } else {
-        tile_id = xcd_tile_index();
-    }
     const int ntiles = ntx * ((h + VIF_TH - 1) / VIF_TH);
     const int x0 = (tile_id % ntx) * VIF_TW, y0 = (tile_id / ntx) * VIF_TH;
     const float *fr = ref + (size_t)blockIdx.z * frame_stride;
@@ -551,6 +550,41 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_kern
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
 }
 
+#define VIF_KERNEL_PARAMS const float *__restrict__ ref, const float *__restrict__ dis, size_t frame_stride, int row_stride, int w, int h, \
+                          double *__restrict__ partial, float *__restrict__ oref, float *__restrict__ odis,                          \
+                          size_t out_frame_stride, int out_row_stride
+#define VIF_KERNEL_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+
+// ORDER_SCALAR / ORDER_FMA: one workgroup per tile, every sample in the same order.
+template <int FW, bool OFFSET, int ORDER>
+__global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_kernel(VIF_KERNEL_PARAMS)
+{
+    __shared__ __attribute__((aligned(16))) float smem[VifGeom<FW>::SMEM_FLOATS + 16 + VifGeom<FW>::D_FLOATS];
+    vif_tile<FW, OFFSET, ORDER, false>(smem, xcd_tile_index(), VIF_KERNEL_ARGS);
+}
+
+// ORDER_AVX: one launch, two tile sets.  Workgroups [0, nb_pad) take the border-frame tiles (the first bg.ntiles of them;
+// nb_pad rounds that up to a multiple of 8 so the XCD mapping of the rest is undisturbed), where every sample picks its
+// order as convolution_f32_avx_s_1d does; the others take the interior rectangle [1, tx_r) x [1, ty_b), all in the
+// vector order.  The border tiles cost more each and go first, so they are not the launch's tail.
+template <int FW, bool OFFSET>
+__global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_kernel(VIF_KERNEL_PARAMS, int nb_pad)
+{
+    __shared__ __attribute__((aligned(16))) float smem[VifGeom<FW>::SMEM_FLOATS + 16 + VifGeom<FW>::D_FLOATS];
+    const BorderGeom bg = border_geom(w, h, FW / 2, VIF_TW, VIF_TH);
+    const int ntx = bg.ntx;
+    const int b = blockIdx.x;
+    if (b < nb_pad) {
+        if (b >= bg.ntiles) return;                           // padding workgroup
+        int tx, ty;
+        border_tile_at(bg, b, tx, ty);
+        vif_tile<FW, OFFSET, ORDER_AVX, true>(smem, ty * ntx + tx, VIF_KERNEL_ARGS);
+    } else {
+        const int i = xcd_tile_index(b - nb_pad, (int)gridDim.x - nb_pad), iw = bg.tx_r - 1;
+        vif_tile<FW, OFFSET, ORDER_AVX, false>(smem, (1 + i / iw) * ntx + 1 + i % iw, VIF_KERNEL_ARGS);
+    }
+}
+
 // ---------------------------------------------------------------- ADM
 // One workgroup = ADM_SW x ADM_SH coefficient slots (a ADM_TW x ADM_TH interior plus the one-coefficient halo the
 // masking threshold looks at), 256 threads, no staging of the input picture:
@@ -573,7 +607,10 @@ static_assert(ADM_COLS == 128 && ADM_THREADS == 2 * ADM_COLS, "phase 1 maps thre
 
 // One ADM scale, fused (adm.c:132-247 for one value of `scale`): adm_dwt2 x2, adm_decouple, adm_csf x3,
 // adm_cm_thresh, adm_cm and the six adm_sum_cube accumulations.  Only the LL bands go back to HBM.
-template <bool OFFSET>
+// FAST (ORDER_FMA, opt-in): the 4-tap db2 sums with fused multiply-adds; everything after the DWT is unchanged.
+template <bool FAST> __device__ __forceinline__ float db2_acc(float acc, float c, float x) { return FAST ? __builtin_fmaf(c, x, acc) : acc + c * x; }
+
+template <bool OFFSET, bool FAST>
 __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                                    size_t in_frame_stride, int in_row_stride, int w, int h,
                                                                    float *__restrict__ ll_ref, float *__restrict__ ll_dis,
@@ -622,10 +659,10 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
             float lo_d = kDb2Lo[0] * pd[2 * i], hi_d = kDb2Hi[0] * pd[2 * i];
 #pragma unroll
             for (int t = 1; t < 4; ++t) {
-                lo_r = lo_r + kDb2Lo[t] * pr[2 * i + t];
-                hi_r = hi_r + kDb2Hi[t] * pr[2 * i + t];
-                lo_d = lo_d + kDb2Lo[t] * pd[2 * i + t];
-                hi_d = hi_d + kDb2Hi[t] * pd[2 * i + t];
+                lo_r = db2_acc<FAST>(lo_r, kDb2Lo[t], pr[2 * i + t]);
+                hi_r = db2_acc<FAST>(hi_r, kDb2Hi[t], pr[2 * i + t]);
+                lo_d = db2_acc<FAST>(lo_d, kDb2Lo[t], pd[2 * i + t]);
+                hi_d = db2_acc<FAST>(hi_d, kDb2Hi[t], pd[2 * i + t]);
             }
             vdst[i * 2 * ADM_VP] = make_float4(lo_r, hi_r, lo_d, hi_d);
         }
@@ -651,10 +688,10 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
         float dh = kDb2Lo[0] * q[0].w, dd = kDb2Hi[0] * q[0].w;
 #pragma unroll
         for (int t = 1; t < 4; ++t) {
-            ra = ra + kDb2Lo[t] * q[t].x;   rv = rv + kDb2Hi[t] * q[t].x;
-            rh = rh + kDb2Lo[t] * q[t].y;   rd = rd + kDb2Hi[t] * q[t].y;
-            da = da + kDb2Lo[t] * q[t].z;   dv = dv + kDb2Hi[t] * q[t].z;
-            dh = dh + kDb2Lo[t] * q[t].w;   dd = dd + kDb2Hi[t] * q[t].w;
+            ra = db2_acc<FAST>(ra, kDb2Lo[t], q[t].x);   rv = db2_acc<FAST>(rv, kDb2Hi[t], q[t].x);
+            rh = db2_acc<FAST>(rh, kDb2Lo[t], q[t].y);   rd = db2_acc<FAST>(rd, kDb2Hi[t], q[t].y);
+            da = db2_acc<FAST>(da, kDb2Lo[t], q[t].z);   dv = db2_acc<FAST>(dv, kDb2Hi[t], q[t].z);
+            dh = db2_acc<FAST>(dh, kDb2Lo[t], q[t].w);   dd = db2_acc<FAST>(dd, kDb2Hi[t], q[t].w);
         }
         const bool interior = lane_on && tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH && cxr < bw && cyr < bh;
         if (interior && ll_ref) {
@@ -1202,15 +1239,13 @@ hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const floa
     static const int fw[4] = { 17, 9, 5, 3 };
     const dim3 g = grid_flat(w, h, VIF_TW, VIF_TH, nframes);
     const BorderGeom bg = border_geom(w, h, fw[scale] / 2, VIF_TW, VIF_TH);
-    const dim3 gb(bg.ntiles, 1, nframes), gi((bg.tx_r - 1) * (bg.ty_b - 1), 1, nframes);   // border frame, interior rectangle
+    const int nb = bg.ntiles, ni = (bg.tx_r - 1) * (bg.ty_b - 1), nb_pad = ni > 0 ? (nb + 7) / 8 * 8 : nb;
+    const dim3 gm(nb_pad + ni, 1, nframes);                   // border-frame tiles (padded) first, then the interior rectangle
 #define VIF_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
 #define VIF_STAT(FW, OFF)                                                                              \
-    if (order == ORDER_SCALAR) {                                                                       \
-        vif_stat_kernel<FW, OFF, ORDER_SCALAR, false><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);             \
-    } else {                                                                                           \
-        if (gi.x > 0) vif_stat_kernel<FW, OFF, ORDER_AVX, false><<<gi, VIF_THREADS, 0, s>>>(VIF_ARGS); \
-        if (gb.x > 0) vif_stat_kernel<FW, OFF, ORDER_AVX, true><<<gb, VIF_THREADS, 0, s>>>(VIF_ARGS);  \
-    }
+    if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
+    else if (order == ORDER_FMA) vif_stat_kernel<FW, OFF, ORDER_FMA><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
+    else vif_stat_avx_kernel<FW, OFF><<<gm, VIF_THREADS, 0, s>>>(VIF_ARGS, nb_pad)
     switch (scale) {
     case 0: VIF_STAT(17, true); break;
     case 1: VIF_STAT(9, false); break;
@@ -1222,19 +1257,22 @@ hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const floa
     return hipGetLastError();
 }
 
-hipError_t vk_launch_adm_scale(int scale, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+hipError_t vk_launch_adm_scale(int scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
                                double *partial, hipStream_t s)
 {
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     const dim3 g = grid_flat(bw, bh, ADM_TW, ADM_TH, nframes);
-    if (scale == 0)
-        adm_scale_kernel<true><<<g, ADM_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride,
-                                                         ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial);
-    else
-        adm_scale_kernel<false><<<g, ADM_THREADS, 0, s>>>(ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride,
-                                                          ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial);
+#define ADM_ARGS ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride, ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial
+    if (order == ORDER_FMA) {
+        if (scale == 0) adm_scale_kernel<true, true><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
+        else adm_scale_kernel<false, true><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
+    } else {
+        if (scale == 0) adm_scale_kernel<true, false><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
+        else adm_scale_kernel<false, false><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
+    }
+#undef ADM_ARGS
     return hipGetLastError();
 }
 
@@ -1252,6 +1290,8 @@ hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, in
     const dim3 g(tiles, (nframes + chunk - 1) / chunk, 1);
     if (order == ORDER_SCALAR)
         motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
+    else if (order == ORDER_FMA)
+        motion_kernel<ORDER_FMA><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
     else
         motion_kernel<ORDER_AVX><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
     return hipGetLastError();
