@@ -6,8 +6,10 @@
  * fast-math: every multiply and add below is meant to round separately, as the reference's
  * x86-64 SSE/AVX build does (no FMA: wrapper/Makefile:47-55 passes only -mavx).
  *
- * Parity status: PINNED against oracle/_ref (tests/test_oracle_vs_ref.py) and the committed
- * golden fixtures generated from it (tests/golden/).
+ * Parity status: PINNED against oracle/_ref (tests/test_oracle_vs_ref.py), the committed
+ * golden fixtures generated from it (tests/golden/), and the reference's own known-answer tests
+ * for its flat and checkerboard clips (python/test/feature_test.py:566-719,
+ * quality_runner_test.py:333-432; tests/test_reference_pinned.py, tests/test_oracle_golden.py).
  */
 #include "vmaf_oracle.h"
 

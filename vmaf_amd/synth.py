@@ -85,6 +85,22 @@ def make_clip(width, height, frames, seed=1234, bits=8, cuts=(), static=False, p
     return (ref * 4 + dr).astype(np.uint16), (dis * 4 + dd).astype(np.uint16)
 
 
+def checkerboard(width=1920, height=1080, block=10, frames=3, dx=0, dy=0, lo=16, hi=235):
+    """The reference's test clips `checkerboard_<w>_<h>_<block>_<frames>_<dx>_<dy>.yuv` (python/test/resource/yuv; absent
+    from the reference tree, .MISSING_LARGE_BLOBS:1-3), re-derived from the numbers its tests pin for them
+    (python/test/feature_test.py:566-657, quality_runner_test.py:333-389): video-range squares of `block` pixels,
+    luma = lo where floor((x - t - dx) / block) + floor((y - dy) / block) is even, hi elsewhere, i.e. the board moves
+    right by one pixel per frame t and the "_dx_dy" variants are the same board displaced further.  With these
+    parameters the reference's C code reproduces every pinned value of those tests to the printed digits
+    (tests/golden/reference_pinned.json, tests/test_reference_pinned.py).  -> uint8 [frames, height, width]"""
+    y, x = np.mgrid[0:height, 0:width]
+    out = np.empty((frames, height, width), np.uint8)
+    for t in range(frames):
+        par = (np.floor_divide(x - t - dx, block) + np.floor_divide(y - dy, block)) & 1
+        out[t] = np.where(par == 0, lo, hi)
+    return out
+
+
 def to_luma_f32(planes, bits=8):
     """What a read_frame callback delivers (feature/src/common/file_io.c:112-116,159-163):
     8-bit -> value, 10-bit -> value / 4.0, as fp32."""
