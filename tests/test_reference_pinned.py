@@ -81,6 +81,40 @@ def test_oracle_meets_the_reference_tests_pinned_values(case, model_path):
             assert np.all(np.abs(s[:, j] - np.array(PIN[case]["ssim_per_frame"][k])) < 1.5e-6), (k, s[:, j])
 
 
+def test_oracle_meets_the_pinned_scores_of_the_model_and_flag_variants():
+    """quality_runner_test.py:965-1277: score transform, out_lte_in + no clipping, transform disabled, phone model - all on
+    the 'opposite' checkerboard pair."""
+    ref, dis = _clip("opposite")
+    atoms = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX)
+    for v in PIN["opposite"]["variants"]:
+        mp = os.path.join(os.path.dirname(HERE), v["model"])
+        vm, _ = oracle.vmaf_from_atoms(atoms, oracle.load_pkl_model(mp), oracle.load_svm_model(mp + ".model"),
+                                       enable_transform=v["enable_transform"], disable_clip=v["disable_clip"])
+        assert round(abs(float(np.mean(vm)) - v["vmaf"]), v["places"]) == 0, (v, float(np.mean(vm)))
+
+
+@pytest.mark.gpu
+def test_vmafossexec_meets_the_pinned_scores_of_the_model_and_flag_variants(tmp_path):
+    """The same four variants end to end: regenerated yuv420p files -> vmaf_amd/vmafossexec with the reference's flags
+    (--enable-transform / --disable-clip / --phone-model) -> the score it prints.  Held to 1e-4 rather than the reference's
+    four places (5e-5): the exact motion sum is 8.4e-5 below the reference's fp32-accumulated one on this clip (see the engine
+    test below), which moves these scores by up to 7e-5 (32.757364 vs 32.757434); the north-star bar for VMAF is 1e-3."""
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    rp, dp = str(tmp_path / "checkerboard_1920_1080_10_3_0_0.yuv"), str(tmp_path / "checkerboard_1920_1080_10_3_10_0.yuv")
+    synth.write_yuv(rp, synth.checkerboard(1920, 1080, 10, 3, 0, 0), "yuv420p")
+    synth.write_yuv(dp, synth.checkerboard(1920, 1080, 10, 3, 10, 0), "yuv420p")
+    for v in PIN["opposite"]["variants"]:
+        phone = v["model"].startswith("model/")
+        cmd = [os.path.join(root, "vmaf_amd", "vmafossexec"), "yuv420p", "1920", "1080", rp, dp, os.path.join(root, v["model"])]
+        cmd += (["--phone-model"] if phone else ["--enable-transform"] if v["enable_transform"] else []) + (["--disable-clip"] if v["disable_clip"] else [])
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr + p.stdout
+        got = float(re.search(r"VMAF score = ([-0-9.]+)", p.stdout).group(1))
+        assert abs(got - v["vmaf"]) < 1e-4, (v, got)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("order", ["avx", "fma"])
 @pytest.mark.parametrize("case", CASES)
