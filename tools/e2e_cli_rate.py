@@ -32,11 +32,15 @@ def main():
                 g.write(one_d)
         exe = os.path.join(ROOT, "vmaf_amd", "vmafossexec")
         model = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
-        for label, env in (("raw luma hand-over (compute_vmaf_raw)", "0"), ("fp32 read_frame callback (compute_vmaf)", "1")):
+        for label, env in (("raw luma hand-over (compute_vmaf_raw), 8 reader threads", dict(VMAF_HIP_FP32_CALLBACK="0")),
+                           ("raw luma hand-over, 16 reader threads", dict(VMAF_HIP_FP32_CALLBACK="0", VMAF_HIP_READ_THREADS="16")),
+                           ("raw luma hand-over, 8 reader threads, fused order (VMAF_HIP_FAST=1)", dict(VMAF_HIP_FP32_CALLBACK="0", VMAF_HIP_FAST="1")),
+                           ("raw luma hand-over, one reader thread per file (fread)", dict(VMAF_HIP_FP32_CALLBACK="0", VMAF_HIP_READ_THREADS="1")),
+                           ("fp32 read_frame callback (compute_vmaf)", dict(VMAF_HIP_FP32_CALLBACK="1"))):
             for rep in range(2):                                 # second run: page cache and GPU warm
                 t0 = time.perf_counter()
                 p = subprocess.run([exe, "yuv420p", "1920", "1080", rp, dp, model], capture_output=True, text=True,
-                                   env=dict(os.environ, VMAF_HIP_FP32_CALLBACK=env))
+                                   env=dict(os.environ, **env))
                 wall = time.perf_counter() - t0
             fps = float(re.search(r"Exec FPS: ([0-9.]+)", p.stdout).group(1))
             score = float(re.search(r"VMAF score = ([0-9.]+)", p.stdout).group(1))

@@ -85,7 +85,9 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, cons
 
     const std::vector<int> devices = parse_devices();
     const int G = (int)devices.size();
-    int batch = (int)std::min<size_t>(64, std::max<size_t>(4, ((size_t)128 << 20) / plane));
+    // frames per batch: ~32 MB of luma per plane and batch (16 frames of raw 8-bit 1080p).  Larger batches only add
+    // page-locked memory to set up and latency before the first launch; measured with tools/e2e_cli_rate.py
+    int batch = (int)std::min<size_t>(64, std::max<size_t>(4, ((size_t)32 << 20) / plane));
     if (const char *env = std::getenv("VMAF_HIP_BATCH")) { const int v = std::atoi(env); if (v > 0) batch = std::min(v, 4096); }
 
     EngineGuard guard;
