@@ -152,6 +152,33 @@ def test_raw_and_fp32_callbacks_give_identical_logs(name, tmp_path):
     assert logs[0] == logs[1] and len(logs[0]) == len(case["frames"])
 
 
+def test_fifo_inputs_and_reader_thread_settings_give_the_same_log(tmp_path):
+    """Regular files go through the pread reader pool (VMAF_HIP_READ_THREADS, default 8), pipes through the sequential
+    fread path that skips chroma by reading (frame.c:80-124 does the same): identical logs either way."""
+    case = EXEC["default"]
+    rp, dp, w, h = _files(case, tmp_path)
+    model = os.path.join(ROOT, case["model"])
+    logs = []
+    for threads in ("8", "3", "1"):
+        log = str(tmp_path / f"t{threads}.xml")
+        p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, model, "--log", log], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, VMAF_HIP_READ_THREADS=threads))
+        assert p.returncode == 0, p.stderr
+        logs.append(re.sub(r'execFps="[^"]*"', "", open(log).read()))
+    fr, fd = str(tmp_path / "ref.fifo"), str(tmp_path / "dis.fifo")
+    os.mkfifo(fr)
+    os.mkfifo(fd)
+    # the feeders open the FIFOs for writing in their own processes (that open blocks until vmafossexec opens the read end)
+    feeders = [subprocess.Popen(["sh", "-c", 'exec cat "$0" > "$1"', src, dst]) for src, dst in ((rp, fr), (dp, fd))]
+    log = str(tmp_path / "fifo.xml")
+    p = subprocess.run([OURS, case["fmt"], str(w), str(h), fr, fd, model, "--log", log], capture_output=True, text=True, timeout=120)
+    for f in feeders:
+        f.wait(timeout=30)
+    assert p.returncode == 0, p.stderr
+    logs.append(re.sub(r'execFps="[^"]*"', "", open(log).read()))
+    assert all(x == logs[0] for x in logs[1:])
+
+
 def test_fast_mode_env_keeps_the_cli_inside_the_tolerances(tmp_path):
     """VMAF_HIP_FAST=1: compute_vmaf runs the fused order (conv order 2).  Same schema, values within 1e-4 / 1e-3 of what
     the reference's vmafossexec printed for the same files; --disable-avx still selects the reference's scalar order."""
