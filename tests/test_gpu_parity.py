@@ -334,6 +334,36 @@ def test_two_async_calls_in_flight():
         assert np.array_equal(got.reshape(6, 20), want)
 
 
+def test_engines_on_concurrent_host_threads():
+    """Engines are independent objects (own streams, buffers, pending slots; the error string is thread-local): four host
+    threads, each with its own engine and clip, running at the same time give bit for bit what they give alone."""
+    import threading
+    clips = [_clip(320 + 16 * k, 180 + 8 * k, 6, seed=40 + k) for k in range(4)]
+    alone = []
+    for ref, dis in clips:
+        with vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) as e:
+            alone.append(e.extract(ref, dis))
+    got, errs = [None] * 4, []
+
+    def work(k):
+        try:
+            ref, dis = clips[k]
+            with vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) as e:
+                for _ in range(5):
+                    got[k] = e.extract(ref, dis)
+        except Exception as ex:                                   # noqa: BLE001 - reported below
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert not errs, errs
+    for k in range(4):
+        assert np.array_equal(got[k], alone[k])
+
+
 @pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 101, 75), (10, 320, 180)])
 def test_ansnr_matches_oracle(bits, w, h):
     """feature/src/ansnr.c through the GPU (the `ansnr` / `anpsnr` atoms of feature/src/all.c) against the C
