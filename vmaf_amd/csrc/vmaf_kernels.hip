@@ -141,71 +141,6 @@ __device__ __forceinline__ int xcd_tile_index(int b, int nt)
 }
 __device__ __forceinline__ int xcd_tile_index() { return xcd_tile_index(blockIdx.x, gridDim.x); }
 
-// ---------------------------------------------------------------- tile staging
-// Stage an IH x IW window (IW % 4 == 0) of one or two planes, whose top-left corner is image pixel
-// (gx0, gy0), into LDS (dense rows of IW floats).  Windows inside the image and 16-byte aligned take the
-// float4 path; windows touching the border take the scalar path with the reference's mirror rule.
-// Either way every global load of a thread is in flight before its first LDS write (one memory round
-// trip per tile instead of one per element).
-template <int IH, int IW, int NT, bool OFFSET, bool TWO>
-__device__ __forceinline__ void stage_tile(const float *__restrict__ fr, const float *__restrict__ fd, int row_stride, int w, int h,
-                                           int gx0, int gy0, float *in_r, float *in_d)
-{
-    static_assert(IW % 4 == 0, "staged rows are whole float4s");
-    constexpr int N4 = IH * IW / 4, IT4 = (N4 + NT - 1) / NT;
-    constexpr int N1 = IH * IW, IT1 = (N1 + NT - 1) / NT;
-    const int tid = threadIdx.x;
-    const bool fast = gx0 >= 0 && gy0 >= 0 && gx0 + IW <= w && gy0 + IH <= h && ((gx0 | row_stride) & 3) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(fr) | (TWO ? reinterpret_cast<uintptr_t>(fd) : 0)) & 15) == 0;
-    if (fast) {
-        float4 a[IT4], b[IT4];
-#pragma unroll
-        for (int it = 0; it < IT4; ++it) {
-            const int idx = tid + it * NT;
-            if (idx < N4) {
-                const int ly = idx / (IW / 4), l4 = idx - ly * (IW / 4);
-                const size_t g = (size_t)(gy0 + ly) * row_stride + gx0 + 4 * l4;
-                a[it] = *reinterpret_cast<const float4 *>(fr + g);
-                if (TWO) b[it] = *reinterpret_cast<const float4 *>(fd + g);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < IT4; ++it) {
-            const int idx = tid + it * NT;
-            if (idx < N4) {
-                float4 x = a[it];
-                if (OFFSET) { x.x = x.x + -128.0f; x.y = x.y + -128.0f; x.z = x.z + -128.0f; x.w = x.w + -128.0f; }   // offset_image, combo.c:236-237
-                *reinterpret_cast<float4 *>(in_r + 4 * idx) = x;
-                if (TWO) {
-                    float4 y = b[it];
-                    if (OFFSET) { y.x = y.x + -128.0f; y.y = y.y + -128.0f; y.z = y.z + -128.0f; y.w = y.w + -128.0f; }
-                    *reinterpret_cast<float4 *>(in_d + 4 * idx) = y;
-                }
-            }
-        }
-    } else {
-        float a[IT1], b[IT1];
-#pragma unroll
-        for (int it = 0; it < IT1; ++it) {
-            const int idx = tid + it * NT;
-            if (idx < N1) {
-                const int ly = idx / IW, lx = idx - ly * IW;
-                const size_t g = (size_t)mirror_idx(gy0 + ly, h) * row_stride + mirror_idx(gx0 + lx, w);
-                a[it] = fr[g];
-                if (TWO) b[it] = fd[g];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < IT1; ++it) {
-            const int idx = tid + it * NT;
-            if (idx < N1) {
-                in_r[idx] = OFFSET ? a[it] + -128.0f : a[it];
-                if (TWO) in_d[idx] = OFFSET ? b[it] + -128.0f : b[it];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- block reduction (deterministic)
 template <int K, int NWAVES>
 __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *red /* NWAVES*K doubles of LDS */, double *out)
@@ -307,36 +242,12 @@ __device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float
     }
 }
 
-// Tile 48 x 32 with 256 threads: the vertical pass has (48 + 2*8) * (32/8) = 256 items at 17 taps and the
-// horizontal pass 32 rows * (48/6) strips = 256 items, so all four waves work in both phases; 48 divides
-// every level of the 1080p / 4K pyramids (1920, 960, 480, 240).
+// Tile 48 x 32 with 256 threads = four waves of 48 x 8: a wave's vertical pass has 48 + 2*8 = 64 columns at 17 taps
+// (one per lane) and its horizontal pass 8 rows * (48/6) strips = 64 items; 48 divides every level of the 1080p / 4K
+// pyramids (1920, 960, 480, 240).
 constexpr int VIF_TW = 48, VIF_TH = 32, VIF_THREADS = 256, VIF_SV = 8, VIF_SH = 6;
 constexpr int VIF_WAVES_PER_SIMD = 4;                         // HIP: 2nd __launch_bounds__ argument = min waves per SIMD;
-                                                              // 32 KB LDS and <= 128 VGPRs per workgroup -> 4 workgroups per CU
-
-template <int FW> struct VifGeom {
-    static constexpr int R = FW / 2;
-    static constexpr int HP = (R + 3) / 4 * 4;                // horizontal halo rounded up to whole float4s
-    static constexpr int IW = VIF_TW + 2 * HP;                // staged columns
-    static constexpr int IH = VIF_TH + 2 * R;                 // staged rows
-    static constexpr int VW = VIF_TW + 2 * R;                 // columns the vertical pass produces
-    static constexpr int VS = ((VW / 2) & 1) ? VW : VW + 2;   // 2*odd >= VW: rows of a half-wave hit distinct bank pairs (ds_read_b64)
-    static constexpr int NV = VIF_SH + 2 * R;                 // values one horizontal strip needs
-    static constexpr int NV2 = NV / 2;
-    static constexpr int DFW = FW == 17 ? 9 : FW == 9 ? 5 : FW == 5 ? 3 : 0;   // filter of the next scale (vif.c:137-138,160-161)
-    static constexpr int RD = DFW / 2;
-    static constexpr int DVW = VIF_TW + 2 * RD;               // columns the decimation's vertical pass produces
-    static constexpr int D_FLOATS = DFW ? 2 * (VIF_TH / 2) * DVW : 0;
-    static constexpr int DSH = 3;                             // decimated outputs per thread, horizontal pass
-    static_assert(2 * (VIF_TH / 2) * (VIF_TW / 2 / DSH) == VIF_THREADS && (VIF_TW / 2) % DSH == 0, "one decimation strip per thread");
-    static constexpr int IN_FLOATS = 2 * IH * IW;
-    static constexpr int VQ = 3;                              // planes of vertical results in LDS at a time (of 5: two rounds)
-    static constexpr int V_FLOATS = VQ * VIF_TH * VS;
-    static constexpr int SMEM_FLOATS = (IN_FLOATS > V_FLOATS ? IN_FLOATS : V_FLOATS);
-    static_assert(VW * (VIF_TH / VIF_SV) <= VIF_THREADS, "one vertical item per thread");
-    static_assert(VW % 2 == 0 && NV % 2 == 0 && VIF_SH % 2 == 0, "float2 reads");
-    static_assert(VIF_TH * (VIF_TW / VIF_SH) == VIF_THREADS, "one horizontal item per thread");
-};
+                                                              // 35 KB LDS and <= 128 VGPRs per workgroup -> 4 workgroups per CU
 
 // 1-D filter over a register window: out[o] = sum_k f[k] * v[o + k], in the scalar or the vector order
 template <int FW, int NOUT, int ORDER>
@@ -393,110 +304,159 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
     }
 }
 
-// Fused VIF scale kernel. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products,
-// three filtered moments, vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.
-// From the same staged tile it also produces the next scale's input (vif.c:157-186): blur with the NEXT
-// scale's filter, evaluated at even rows/columns only, so ref/dis are read from HBM once per scale.
+#define VIF_KERNEL_PARAMS const float *__restrict__ ref, const float *__restrict__ dis, size_t frame_stride, int row_stride, int w, int h, \
+                          double *__restrict__ partial, float *__restrict__ oref, float *__restrict__ odis,                          \
+                          size_t out_frame_stride, int out_row_stride
+#define VIF_KERNEL_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+
+// ---------------------------------------------------------------- VIF
+// Fused VIF scale. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products, three filtered moments,
+// vif_statistic and vif_sum - none of the 11 intermediate planes touches HBM.  From the same input rows it also produces
+// the next scale's input (vif.c:157-186): blur with the NEXT scale's filter, evaluated at even rows/columns only, so
+// ref/dis are read from HBM once per scale.
 // ORDER_AVX has two tile sets: BORDER = false for the tiles whose every sample is in the vector order, BORDER = true
 // for the border-frame tiles, where every sample picks its order exactly as convolution_f32_avx_s_1d does
 // (convolution_avx.c:806-836); both write partial[frame][tile] and the decimated planes of their own tiles.
-// One workgroup runs vif_tile once, for the tile its kernel (below) picks.
-template <int FW, bool OFFSET, int ORDER, bool BORDER>
-__device__ __forceinline__ void vif_tile(float *smem, int tile_id, const float *__restrict__ ref, const float *__restrict__ dis,
-                                         size_t frame_stride, int row_stride, int w, int h,
-                                         double *__restrict__ partial,
-                                         float *__restrict__ oref, float *__restrict__ odis,
-                                         size_t out_frame_stride, int out_row_stride)
-{
-    using G = VifGeom<FW>;
-    constexpr int R = G::R, IW = G::IW, IH = G::IH, VS = G::VS;
-    constexpr int DFW = G::DFW, RD = G::RD, DVW = G::DVW;
-    float *in_r = smem, *in_d = smem + IH * IW;
-    float *dv_s = smem + G::SMEM_FLOATS + 16;                 // decimation: vertical results, [2][TH/2][DVW]
-    double *red = reinterpret_cast<double *>(smem);           // reused after the last LDS read
+// The four waves of a workgroup never wait for each other: every wave owns 8 output rows x 48 columns of the workgroup's
+// 48x32 tile from the first load to the last sum.
+//   vertical pass     lane = one of the 64 columns x0-R .. (needs 48+2R <= 64), its 8+2R input rows of ref and dis straight
+//                     from global memory (buffer loads: frame descriptor + wave-uniform row offset in SGPRs, mirrored
+//                     rows/columns by index), no staging tile; five quantities x 8 rows in registers
+//   transpose         through the wave's own 8 x 72-float LDS rows, three planes at a time; only wave-level ordering
+//                     (LDS serves one wave's instructions in order) - no __syncthreads until the final reduction
+//   horizontal pass   lane = (row, strip of 6 columns); row pitch 72 = 8 mod 32 spreads the 32 lanes of a ds_read_b64
+//                     pass over all banks exactly twice
+//   decimation        the next scale's planes for the wave's 4 even rows, same two-step scheme
+// Waves whose rows lie below the picture (last tile row) skip everything but the reduction.
+constexpr int VWV_TH = 8;                                    // output rows per wave
+constexpr int VWV_VS = 72;                                   // LDS row pitch of the vertical results
+static_assert(VWV_TH == VIF_SV && VWV_TH * (VIF_THREADS / 64) == VIF_TH, "four waves of 8 rows make the 48x32 tile");
 
-    const int tid = threadIdx.x;
+template <int FW> struct VifWaveGeom {
+    static constexpr int R = FW / 2;
+    static constexpr int VW = VIF_TW + 2 * R;                 // columns the vertical pass produces (<= 64 lanes)
+    static constexpr int NV = VIF_SH + 2 * R, NV2 = NV / 2;
+    static constexpr int DFW = FW == 17 ? 9 : FW == 9 ? 5 : FW == 5 ? 3 : 0;
+    static constexpr int RD = DFW / 2;
+    static constexpr int DVW = VIF_TW + 2 * RD;
+    static constexpr int DSH = 3;
+    static constexpr int VQ = 3;
+    static constexpr int V_FLOATS = VQ * VWV_TH * VWV_VS;
+    static constexpr int D_FLOATS = DFW ? 2 * (VWV_TH / 2) * DVW : 0;
+    static constexpr int WAVE_FLOATS = (V_FLOATS + D_FLOATS + 3) / 4 * 4;
+    static_assert(VW <= 64 && VW <= VWV_VS && NV % 2 == 0, "one lane per column, float2 reads");
+    static_assert(VWV_TH * (VIF_TW / VIF_SH) == 64, "one horizontal item per lane");
+    static_assert(2 * (VWV_TH / 2) * (VIF_TW / 2 / DSH) == 64, "one decimation strip per lane");
+};
+
+// orders the LDS traffic of ONE wave: its earlier writes are visible to its later reads (the LDS executes a wave's
+// instructions in order; this only keeps the compiler from moving them across)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int FW, bool OFFSET, int ORDER, bool BORDER>
+__device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile_id, const float *__restrict__ ref, const float *__restrict__ dis,
+                                              size_t frame_stride, int row_stride, int w, int h,
+                                              double *__restrict__ partial,
+                                              float *__restrict__ oref, float *__restrict__ odis,
+                                              size_t out_frame_stride, int out_row_stride)
+{
+    using G = VifWaveGeom<FW>;
+    constexpr int R = G::R, VS = VWV_VS, DFW = G::DFW, RD = G::RD, DVW = G::DVW;
+    constexpr int NW = VWV_TH + 2 * R;                        // input rows of one wave
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *vout = smem + wv * G::WAVE_FLOATS;
+    float *dv_s = vout + G::V_FLOATS;                         // decimation: vertical results, [2][4][DVW]
     const int ntx = (w + VIF_TW - 1) / VIF_TW;
     const int ntiles = ntx * ((h + VIF_TH - 1) / VIF_TH);
-    const int x0 = (tile_id % ntx) * VIF_TW, y0 = (tile_id / ntx) * VIF_TH;
-    const float *fr = ref + (size_t)blockIdx.z * frame_stride;
-    const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+    const int x0 = (tile_id % ntx) * VIF_TW;
+    const int y0 = (tile_id / ntx) * VIF_TH + wv * VWV_TH;    // this wave's first output row (wave-uniform)
+    double acc[2] = { 0.0, 0.0 };
 
-    // ---- stage tile + halo (mirrored at the image border) into LDS
-    stage_tile<IH, IW, VIF_THREADS, OFFSET, true>(fr, fd, row_stride, w, h, x0 - G::HP, y0 - R, in_r, in_d);
-    __syncthreads();
-
-    // ---- vertical pass: one column, VIF_SV output rows, five quantities, all in registers
-    float vo[5][VIF_SV];
-    const int vc = tid % G::VW, vs = tid / G::VW;
-    const bool vactive = tid < G::VW * (VIF_TH / VIF_SV);
-    if (vactive) {
-        float rv[VIF_SV + 2 * R], dv[VIF_SV + 2 * R], t[VIF_SV + 2 * R];
+    if (y0 < h) {
+        const float *fr = ref + (size_t)blockIdx.z * frame_stride;
+        const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+        // ---- vertical pass: lane = column x0 - R + lane
+        float vo[5][VWV_TH];
+        const int vc = lane;
+        const int gxc = mirror_idx(x0 - R + vc, w);
+        {
+            float rv[NW], dv[NW], t[NW];
+            const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
+            const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
 #pragma unroll
-        for (int i = 0; i < VIF_SV + 2 * R; ++i) {
-            rv[i] = in_r[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
-            dv[i] = in_d[(vs * VIF_SV + i) * IW + vc + (G::HP - R)];
+            for (int i = 0; i < NW; ++i) {
+                const int roff = mirror_idx(y0 - R + i, h) * row_stride * 4;       // wave-uniform: SGPR
+                rv[i] = buf_load(br, gxc * 4, roff);
+                dv[i] = buf_load(bd, gxc * 4, roff);
+            }
+            if (OFFSET) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) { rv[i] = rv[i] + -128.0f; dv[i] = dv[i] + -128.0f; }   // offset_image, combo.c:236-237
+            }
+            if (DFW > 0) {
+                // decimation, vertical pass at the even rows (y0 is even): output row y0 + 2i is window element R + 2i
+                const bool dcol = vc >= R - RD && vc < R - RD + DVW;
+                const bool col_avx = ORDER == ORDER_AVX && avx_vcol_ok(gxc, w);
+#pragma unroll
+                for (int i = 0; i < VWV_TH / 2; ++i) {
+                    const bool avx = col_avx && avx_row_ok(y0 + 2 * i, h, RD);
+                    const float a = taps_sel<DFW ? DFW : 3, false, ORDER>(rv + R - RD + 2 * i, 1, avx);
+                    const float b = taps_sel<DFW ? DFW : 3, false, ORDER>(dv + R - RD + 2 * i, 1, avx);
+                    if (dcol) {
+                        dv_s[i * DVW + vc - (R - RD)] = a;
+                        dv_s[(VWV_TH / 2 + i) * DVW + vc - (R - RD)] = b;
+                    }
+                }
+            }
+            unsigned vmask = 0;                               // BORDER: vector order iff row and column both allow it
+            if (BORDER && avx_vcol_ok(gxc, w)) {
+#pragma unroll
+                for (int o = 0; o < VWV_TH; ++o) vmask |= avx_row_ok(y0 + o, h, R) ? 1u << o : 0u;
+            }
+#define VIF_VPASS(src, q)                                                  \
+            if (BORDER) taps_window_sel<FW, VWV_TH>(src, vo[q], vmask);    \
+            else taps_window<FW, VWV_TH, ORDER>(src, vo[q])
+            VIF_VPASS(rv, 0);
+            VIF_VPASS(dv, 1);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) t[i] = rv[i] * rv[i];
+            VIF_VPASS(t, 2);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) t[i] = dv[i] * dv[i];
+            VIF_VPASS(t, 3);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) t[i] = rv[i] * dv[i];
+            VIF_VPASS(t, 4);
+#undef VIF_VPASS
         }
-        if (DFW > 0 && vc >= R - RD && vc < R - RD + DVW) {
-            // decimation, vertical pass at the even rows (y0 is even) out of the same register windows:
-            // output row y0 + vs*SV + 2i is window element R + 2i, columns x0-RD .. x0+TW+RD-1
-            const bool col_avx = ORDER == ORDER_AVX && avx_vcol_ok(mirror_idx(x0 - R + vc, w), w);
+        if (DFW > 0) {
+            // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes;
+            // lane = (plane, output row, strip of DSH outputs), taps from a register window
+            wave_lds_sync();
+            constexpr int DSH = G::DSH, DNW = 2 * (DSH - 1) + (DFW ? DFW : 1);
+            const int pl = lane >> 5, oy = (lane >> 3) & 3, ox0 = (lane & 7) * DSH;
+            const int ow = w / 2, oh = h / 2, dend = avx_hcol_end(w, RD);
+            const float *src = dv_s + (pl * (VWV_TH / 2) + oy) * DVW + 2 * ox0;
+            float dw[DNW];
 #pragma unroll
-            for (int i = 0; i < VIF_SV / 2; ++i) {
-                const bool avx = col_avx && avx_row_ok(y0 + vs * VIF_SV + 2 * i, h, RD);
-                const int o = (vs * (VIF_SV / 2) + i) * DVW + vc - (R - RD);
-                dv_s[o] = taps_sel<DFW ? DFW : 3, false, ORDER>(rv + R - RD + 2 * i, 1, avx);
-                dv_s[(VIF_TH / 2) * DVW + o] = taps_sel<DFW ? DFW : 3, false, ORDER>(dv + R - RD + 2 * i, 1, avx);
+            for (int k = 0; k < DNW; ++k) dw[k] = src[k];
+            const int gy = y0 / 2 + oy;
+            float *dst = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + x0 / 2 + ox0;
+#pragma unroll
+            for (int o = 0; o < DSH; ++o) {
+                const int sx = x0 + 2 * (ox0 + o);
+                const float val = taps_sel<DFW ? DFW : 3, false, ORDER>(dw + 2 * o, 1, ORDER == ORDER_AVX && sx >= RD && sx < dend);
+                if (x0 / 2 + ox0 + o < ow && gy < oh) dst[o] = val;
             }
         }
-        unsigned vmask = 0;                                   // BORDER: vector order iff row and column both allow it
-        if (BORDER && avx_vcol_ok(mirror_idx(x0 - R + vc, w), w)) {
-#pragma unroll
-            for (int o = 0; o < VIF_SV; ++o) vmask |= avx_row_ok(y0 + vs * VIF_SV + o, h, R) ? 1u << o : 0u;
-        }
-#define VIF_VPASS(src, q)                                                  \
-        if (BORDER) taps_window_sel<FW, VIF_SV>(src, vo[q], vmask);        \
-        else taps_window<FW, VIF_SV, ORDER>(src, vo[q])
-        VIF_VPASS(rv, 0);
-        VIF_VPASS(dv, 1);
-#pragma unroll
-        for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * rv[i];
-        VIF_VPASS(t, 2);
-#pragma unroll
-        for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = dv[i] * dv[i];
-        VIF_VPASS(t, 3);
-#pragma unroll
-        for (int i = 0; i < VIF_SV + 2 * R; ++i) t[i] = rv[i] * dv[i];
-        VIF_VPASS(t, 4);
-#undef VIF_VPASS
-    }
-    __syncthreads();                                          // input tile fully consumed: alias it
-    float *vout = smem;
-    if (DFW > 0) {
-        // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes;
-        // thread = (plane, output row, strip of DSH outputs), taps from a register window
-        constexpr int DSH = G::DSH, DNW = 2 * (DSH - 1) + (DFW ? DFW : 1);
-        const int pl = tid / ((VIF_TH / 2) * (VIF_TW / 2 / DSH)), rem = tid - pl * ((VIF_TH / 2) * (VIF_TW / 2 / DSH));
-        const int oy = rem / (VIF_TW / 2 / DSH), ox0 = (rem - oy * (VIF_TW / 2 / DSH)) * DSH;
-        const int ow = w / 2, oh = h / 2, dend = avx_hcol_end(w, RD);
-        const float *src = dv_s + (pl * (VIF_TH / 2) + oy) * DVW + 2 * ox0;
-        float dw[DNW];
-#pragma unroll
-        for (int k = 0; k < DNW; ++k) dw[k] = src[k];
-        const int gy = y0 / 2 + oy;
-        float *dst = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gy * out_row_stride + x0 / 2 + ox0;
-#pragma unroll
-        for (int o = 0; o < DSH; ++o) {
-            const int sx = x0 + 2 * (ox0 + o);
-            const float val = taps_sel<DFW ? DFW : 3, false, ORDER>(dw + 2 * o, 1, ORDER == ORDER_AVX && sx >= RD && sx < dend);
-            if (x0 / 2 + ox0 + o < ow && gy < oh) dst[o] = val;
-        }
-    }
-    // ---- horizontal pass: one row, VIF_SH output columns.  The five planes of vertical results go through LDS in
-    // two rounds ({mu1, mu2, xx}, then {yy, xy}): 3 planes of LDS instead of 5 let four workgroups share a CU.
-    double acc[2] = { 0.0, 0.0 };
-    {
-        const int row = tid % VIF_TH, strip = tid / VIF_TH;
+        // ---- horizontal pass: lane = (row, strip of VIF_SH columns); planes go through LDS in rounds of VQ
+        const int row = lane & 7, strip = lane >> 3;
         float ho[5][VIF_SH];
         unsigned hmask = 0;
         if (BORDER) {
@@ -511,21 +471,19 @@ __device__ __forceinline__ void vif_tile(float *smem, int tile_id, const float *
         for (int round = 0; round < (5 + G::VQ - 1) / G::VQ; ++round) {
             constexpr int VQ = G::VQ;
             const int q0 = round * VQ, nq = 5 - q0 < VQ ? 5 - q0 : VQ;
-            if (round) __syncthreads();                       // round 0 fully read
-            if (vactive) {
+            wave_lds_sync();                                  // the previous round's reads stay before these writes
 #pragma unroll
-                for (int q = 0; q < VQ; ++q)
-                    if (q < nq) {
+            for (int q = 0; q < VQ; ++q)
+                if (q < nq) {
 #pragma unroll
-                        for (int o = 0; o < VIF_SV; ++o) vout[(q * VIF_TH + vs * VIF_SV + o) * VS + vc] = vo[q0 + q][o];
-                    }
-            }
-            __syncthreads();
+                    for (int o = 0; o < VWV_TH; ++o) vout[(q * VWV_TH + o) * VS + vc] = vo[q0 + q][o];
+                }
+            wave_lds_sync();
 #pragma unroll
             for (int q = 0; q < VQ; ++q)
                 if (q < nq) {
                     float v[G::NV];
-                    const float2 *p = reinterpret_cast<const float2 *>(vout + (q * VIF_TH + row) * VS + strip * VIF_SH);
+                    const float2 *p = reinterpret_cast<const float2 *>(vout + (q * VWV_TH + row) * VS + strip * VIF_SH);
 #pragma unroll
                     for (int m = 0; m < G::NV2; ++m) {
                         const float2 f2 = p[m];
@@ -545,32 +503,23 @@ __device__ __forceinline__ void vif_tile(float *smem, int tile_id, const float *
             if (mine) { acc[0] += (double)n; acc[1] += (double)d; }
         }
     }
-    __syncthreads();                                          // vout fully consumed: alias for the reduction
     const size_t tile = (size_t)blockIdx.z * ntiles + tile_id;
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
 }
 
-#define VIF_KERNEL_PARAMS const float *__restrict__ ref, const float *__restrict__ dis, size_t frame_stride, int row_stride, int w, int h, \
-                          double *__restrict__ partial, float *__restrict__ oref, float *__restrict__ odis,                          \
-                          size_t out_frame_stride, int out_row_stride
-#define VIF_KERNEL_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
-
-// ORDER_SCALAR / ORDER_FMA: one workgroup per tile, every sample in the same order.
 template <int FW, bool OFFSET, int ORDER>
 __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_kernel(VIF_KERNEL_PARAMS)
 {
-    __shared__ __attribute__((aligned(16))) float smem[VifGeom<FW>::SMEM_FLOATS + 16 + VifGeom<FW>::D_FLOATS];
-    vif_tile<FW, OFFSET, ORDER, false>(smem, xcd_tile_index(), VIF_KERNEL_ARGS);
+    __shared__ __attribute__((aligned(16))) float smem[(VIF_THREADS / 64) * VifWaveGeom<FW>::WAVE_FLOATS];
+    __shared__ double red[2 * (VIF_THREADS / 64)];
+    vif_wave_tile<FW, OFFSET, ORDER, false>(smem, red, xcd_tile_index(), VIF_KERNEL_ARGS);
 }
 
-// ORDER_AVX: one launch, two tile sets.  Workgroups [0, nb_pad) take the border-frame tiles (the first bg.ntiles of them;
-// nb_pad rounds that up to a multiple of 8 so the XCD mapping of the rest is undisturbed), where every sample picks its
-// order as convolution_f32_avx_s_1d does; the others take the interior rectangle [1, tx_r) x [1, ty_b), all in the
-// vector order.  The border tiles cost more each and go first, so they are not the launch's tail.
 template <int FW, bool OFFSET>
 __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_kernel(VIF_KERNEL_PARAMS, int nb_pad)
 {
-    __shared__ __attribute__((aligned(16))) float smem[VifGeom<FW>::SMEM_FLOATS + 16 + VifGeom<FW>::D_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[(VIF_THREADS / 64) * VifWaveGeom<FW>::WAVE_FLOATS];
+    __shared__ double red[2 * (VIF_THREADS / 64)];
     const BorderGeom bg = border_geom(w, h, FW / 2, VIF_TW, VIF_TH);
     const int ntx = bg.ntx;
     const int b = blockIdx.x;
@@ -578,10 +527,10 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_
         if (b >= bg.ntiles) return;                           // padding workgroup
         int tx, ty;
         border_tile_at(bg, b, tx, ty);
-        vif_tile<FW, OFFSET, ORDER_AVX, true>(smem, ty * ntx + tx, VIF_KERNEL_ARGS);
+        vif_wave_tile<FW, OFFSET, ORDER_AVX, true>(smem, red, ty * ntx + tx, VIF_KERNEL_ARGS);
     } else {
         const int i = xcd_tile_index(b - nb_pad, (int)gridDim.x - nb_pad), iw = bg.tx_r - 1;
-        vif_tile<FW, OFFSET, ORDER_AVX, false>(smem, (1 + i / iw) * ntx + 1 + i % iw, VIF_KERNEL_ARGS);
+        vif_wave_tile<FW, OFFSET, ORDER_AVX, false>(smem, red, (1 + i / iw) * ntx + 1 + i % iw, VIF_KERNEL_ARGS);
     }
 }
 
