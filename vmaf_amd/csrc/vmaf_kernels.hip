@@ -322,14 +322,14 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
 //   vertical pass     lane = one of the 64 columns x0-R .. (needs 48+2R <= 64), its 8+2R input rows of ref and dis straight
 //                     from global memory (buffer loads: frame descriptor + wave-uniform row offset in SGPRs, mirrored
 //                     rows/columns by index), no staging tile; five quantities x 8 rows in registers
-//   transpose         through the wave's own 8 x 72-float LDS rows, three planes at a time; only wave-level ordering
+//   transpose         through the wave's own 8 x 68-float LDS rows, three planes at a time; only wave-level ordering
 //                     (LDS serves one wave's instructions in order) - no __syncthreads until the final reduction
-//   horizontal pass   lane = (row, strip of 6 columns); row pitch 72 = 8 mod 32 spreads the 32 lanes of a ds_read_b64
-//                     pass over all banks exactly twice
+//   horizontal pass   lane = (row, strip of 6 columns); row pitch 68 = 4 mod 32: the 16 lanes (8 rows x 2 strips) that a
+//                     ds_read_b64 serves per cycle start at 16 different even banks (4*row, 4*row + 6)
 //   decimation        the next scale's planes for the wave's 4 even rows, same two-step scheme
 // Waves whose rows lie below the picture (last tile row) skip everything but the reduction.
 constexpr int VWV_TH = 8;                                    // output rows per wave
-constexpr int VWV_VS = 72;                                   // LDS row pitch of the vertical results
+constexpr int VWV_VS = 68;                                   // LDS row pitch of the vertical results: 4 mod 32 (see above)
 static_assert(VWV_TH == VIF_SV && VWV_TH * (VIF_THREADS / 64) == VIF_TH, "four waves of 8 rows make the 48x32 tile");
 
 template <int FW> struct VifWaveGeom {
