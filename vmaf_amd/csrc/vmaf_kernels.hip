@@ -779,7 +779,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntx = (w + MO_TW - 1) / MO_TW;
-    const int tile = blockIdx.x, ntiles = gridDim.x;
+    const int tile = xcd_tile_index(), ntiles = gridDim.x;        // neighbouring tiles share cache lines: keep them on one XCD
     const int x0 = (tile % ntx) * MO_TW, y0 = (tile / ntx) * MO_TH;
     const int f_begin = blockIdx.y * chunk, f_end = min(nframes, f_begin + chunk);
 
