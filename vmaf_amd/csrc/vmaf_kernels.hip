@@ -230,8 +230,11 @@ __device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float
     const float s2 = yyf - m2sq;
     const float s12 = xyf - m12;
     if (s1 < sigma_nsq) {
+        // the reference evaluates 1.0 - p in double and rounds to float (vif_tools.c:248).  A single fp32 subtraction gives
+        // the same bits: for |p| >= 2^-29 the double difference is exact, so both are the correctly rounded 1 - p; for
+        // smaller |p| both round to 1.0f (the float neighbours of 1 are 2^-24 / 2^-23 away)
         const float p = s2 * sigma_max_inv;
-        num = (float)(1.0 - (double)p);
+        num = 1.0f - p;
         den = 1.0f;
     } else {
         const float sv = (s2 + sigma_nsq) * s1;
@@ -499,7 +502,8 @@ __device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile
             const int gx = x0 + strip * VIF_SH + o;
             float n, d;
             vif_pixel(ho[0][o], ho[1][o], ho[2][o], ho[3][o], ho[4][o], n, d);
-            const bool mine = gx < w && gy < h;
+            // the interior tiles of ORDER_AVX lie inside the picture; elsewhere a tile may hang over its right / bottom edge
+            const bool mine = (ORDER == ORDER_AVX && !BORDER) || (gx < w && gy < h);
             if (mine) { acc[0] += (double)n; acc[1] += (double)d; }
         }
     }
