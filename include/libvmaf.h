@@ -32,6 +32,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only these entry points are exported */
 
 double compute_vmaf(char* fmt, int width, int height, int (*read_frame)(float *ref_data, float *main_data, float *temp_data, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method);
 
@@ -64,6 +65,7 @@ int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int
                                 int enable_transform, int device, double *vmaf_out, double *features_out,
                                 char *errbuf, int errbuf_len);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

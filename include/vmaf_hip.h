@@ -23,6 +23,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only these entry points are exported */
 
 #define VMAF_HIP_ATOMS 20
 
@@ -182,6 +183,7 @@ int vmaf_hip_engine_debug_read_plane(vmaf_hip_engine *e, int kind, int level, in
  */
 double vmaf_hip_last_kernel_ms(vmaf_hip_engine *e, int which);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

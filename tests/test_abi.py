@@ -33,6 +33,16 @@ def test_every_declared_symbol_is_exported(header):
         assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
 
 
+def test_nothing_else_is_exported():
+    """Built with -fvisibility=hidden: the dynamic symbol table holds the entry points of include/*.h and nothing of the
+    kernel launchers or C++ internals (the __hip_cuid_* markers come from the HIP toolchain)."""
+    out = subprocess.run(["nm", "-D", "--defined-only", vmaf_amd.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[1] in "TDB"}
+    declared = set(declared_functions("vmaf_hip.h")) | set(declared_functions("libvmaf.h"))
+    extra = {n for n in exported - declared if not n.startswith("__hip_cuid_")}
+    assert not extra, sorted(extra)
+
+
 def test_headers_compile_as_c():
     for header in ("vmaf_hip.h", "libvmaf.h"):
         src = f'#include "{header}"\nint main(void) {{ return 0; }}\n'
