@@ -579,10 +579,31 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
     const int tid = threadIdx.x;
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     const int ntx = (bw + ADM_TW - 1) / ADM_TW;
-    const int tile_id = xcd_tile_index();
+    // XCD-aware order with the tile ROWS dealt round-robin over the eight runs (run k = rows k, k+8, ..): the rows above and
+    // below the centre window are cheap (see in_window below), and contiguous bands would leave the first and last XCD idle
+    int tile_id;
+    {
+        const int nty = (bh + ADM_TH - 1) / ADM_TH;
+        const int i = xcd_tile_index(), p = i / ntx;           // p-th row of the permuted order
+        int row = 0, cum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int nk = (nty - k + 7) / 8;                  // rows in run k
+            if (p >= cum && p < cum + nk) row = k + 8 * (p - cum);
+            cum += nk;
+        }
+        tile_id = row * ntx + (i - p * ntx);
+    }
     const int cx0 = (tile_id % ntx) * ADM_TW, cy0 = (tile_id / ntx) * ADM_TH;   // first interior coefficient
     const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
+    // The six sums only look at the centre window [left, right) x [top, bottom) (adm_sum_cube, adm_tools.c:55-60), and a
+    // coefficient's masked value depends on its 3x3 neighbourhood only, which every workgroup computes for itself.  A
+    // workgroup whose interior coefficients all lie outside the window (28 % of them at 1080p) therefore contributes
+    // nothing but its LL band: it runs the low-pass halves of the two DWT passes and skips everything else.
+    const bool in_window = cx0 < right && cx0 + ADM_TW > left && cy0 < bottom && cy0 + ADM_TH > top;   // workgroup-uniform
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    if (in_window || ll_ref) {
 
     // ---- phase 1: vertical pass (adm_tools.c:313-334), taps of coefficient row cy at pixel rows 2cy-1 .. 2cy+2
     {
@@ -608,14 +629,20 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
 #pragma unroll
         for (int i = 0; i < ADM_RPT; ++i) {
             // sums start from the first product: 0.0f + x == x except for the sign of a zero, which nothing downstream sees
-            float lo_r = kDb2Lo[0] * pr[2 * i], hi_r = kDb2Hi[0] * pr[2 * i];
-            float lo_d = kDb2Lo[0] * pd[2 * i], hi_d = kDb2Hi[0] * pd[2 * i];
+            float lo_r = kDb2Lo[0] * pr[2 * i], lo_d = kDb2Lo[0] * pd[2 * i], hi_r = 0.0f, hi_d = 0.0f;
 #pragma unroll
             for (int t = 1; t < 4; ++t) {
                 lo_r = db2_acc<FAST>(lo_r, kDb2Lo[t], pr[2 * i + t]);
-                hi_r = db2_acc<FAST>(hi_r, kDb2Hi[t], pr[2 * i + t]);
                 lo_d = db2_acc<FAST>(lo_d, kDb2Lo[t], pd[2 * i + t]);
-                hi_d = db2_acc<FAST>(hi_d, kDb2Hi[t], pd[2 * i + t]);
+            }
+            if (in_window) {
+                hi_r = kDb2Hi[0] * pr[2 * i];
+                hi_d = kDb2Hi[0] * pd[2 * i];
+#pragma unroll
+                for (int t = 1; t < 4; ++t) {
+                    hi_r = db2_acc<FAST>(hi_r, kDb2Hi[t], pr[2 * i + t]);
+                    hi_d = db2_acc<FAST>(hi_d, kDb2Hi[t], pd[2 * i + t]);
+                }
             }
             vdst[i * 2 * ADM_VP] = make_float4(lo_r, hi_r, lo_d, hi_d);
         }
@@ -626,6 +653,28 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
     const int tx = tid & 63, wv = tid >> 6;
     const bool lane_on = tx < ADM_SW;
     const int cxr = cx0 - 1 + tx;
+    if (!in_window) {
+        // outside the window: band_a of ref and dis only (adm_tools.c:336-361, the low-pass taps on the low-pass rows)
+#pragma unroll
+        for (int s = 0; s < ADM_SPT; ++s) {
+            const int ty = wv * ADM_SPT + s;
+            const int cyr = cy0 - 1 + ty;
+            const int txc = lane_on ? tx : 0;
+            const float4 *row = vbuf + ty * 2 * ADM_VP;
+            const float4 q[4] = { row[txc], row[ADM_VP + txc], row[txc + 1], row[ADM_VP + txc + 1] };
+            float ra = kDb2Lo[0] * q[0].x, da = kDb2Lo[0] * q[0].z;
+#pragma unroll
+            for (int t = 1; t < 4; ++t) {
+                ra = db2_acc<FAST>(ra, kDb2Lo[t], q[t].x);
+                da = db2_acc<FAST>(da, kDb2Lo[t], q[t].z);
+            }
+            if (lane_on && tx >= 1 && tx <= ADM_TW && ty >= 1 && ty <= ADM_TH && cxr < bw && cyr < bh) {
+                const size_t g = (size_t)blockIdx.z * ll_frame_stride + (size_t)cyr * ll_row_stride + cxr;
+                ll_ref[g] = ra;
+                ll_dis[g] = da;
+            }
+        }
+    } else {
     float keep_r[ADM_SPT][3], keep_o[ADM_SPT][3], p30[ADM_SPT][3], p15[ADM_SPT][3];
     const float cos1sq = (float)(0.99984769515639127 * 0.99984769515639127);   // cos(1 deg)^2, adm_tools.c:82
 #pragma unroll
@@ -702,7 +751,6 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
     __syncthreads();
 
     // ---- phase 3: masking threshold, contrast masking and cube sums for the interior slots
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
     {
         const int r0 = wv * ADM_SPT - 1;                                  // first neighbour row of this thread's slots
         const int xl = max(tx - 1, 0), xr = min(tx + 1, ADM_AW - 1);
@@ -750,6 +798,8 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
             }
         }
     }
+    }   // in_window
+    }   // in_window || ll_ref
     const size_t tile = (size_t)blockIdx.z * gridDim.x + tile_id;
     block_reduce_store_lds<6, ADM_THREADS>(acc, red, partial + tile * 6);    // red aliases vbuf: 12 KB of its 36 KB
 }
