@@ -179,6 +179,27 @@ def test_fifo_inputs_and_reader_thread_settings_give_the_same_log(tmp_path):
     assert all(x == logs[0] for x in logs[1:])
 
 
+def test_plain_c_caller_on_the_drop_in_boundary(tmp_path):
+    """tests/c_caller/c_caller.c: a C program (gcc, no C++ runtime of its own, no HIP headers) that owns the frames and hands
+    them over through read_frame, linked against libvmaf_amd.so like a C host links the reference's libvmaf.  Its score is the
+    reference executable's; a callback failure (return 1) comes back as an error code + message instead of an exception."""
+    case = EXEC["default"]
+    rp, dp, w, h = _files(case, tmp_path)
+    exe = str(tmp_path / "c_caller")
+    libdir = os.path.join(ROOT, "vmaf_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                         os.path.join(HERE, "c_caller", "c_caller.c"), "-o", exe, "-L", libdir, "-lvmaf_amd", f"-Wl,-rpath,{libdir}"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    model = os.path.join(ROOT, case["model"])
+    p = subprocess.run([exe, rp, dp, str(w), str(h), model], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = float(re.search(r"^score ([-0-9.]+)$", p.stdout, re.M).group(1))
+    assert abs(got - case["stdout_score"]) < 1e-3
+    p = subprocess.run([exe, rp, dp, str(w), str(h), model, "2"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and re.search(r"^error .+", p.stdout, re.M), p.stdout + p.stderr
+
+
 def test_fast_mode_env_keeps_the_cli_inside_the_tolerances(tmp_path):
     """VMAF_HIP_FAST=1: compute_vmaf runs the fused order (conv order 2).  Same schema, values within 1e-4 / 1e-3 of what
     the reference's vmafossexec printed for the same files; --disable-avx still selects the reference's scalar order."""
