@@ -122,17 +122,17 @@ def test_truncated_and_missing_inputs(tmp_path):
     frame_bytes = w * h * 3 // 2
     data = open(dp, "rb").read()
     open(dp, "wb").write(data[:3 * frame_bytes])
-    p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, model, "--log", str(tmp_path / "t.xml")], capture_output=True, text=True)
+    p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, model, "--log", str(tmp_path / "t.xml")], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and 'numOfFrames="3"' in open(tmp_path / "t.xml").read()
     # unknown model -> exception text + usage, exit -1 (main.cpp:225-230)
-    p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, "/nonexistent.pkl"], capture_output=True, text=True)
+    p = subprocess.run([OURS, case["fmt"], str(w), str(h), rp, dp, "/nonexistent.pkl"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 255 and "Error: Error loading model (.pkl)" in p.stderr and "Usage:" in p.stderr
     # --ms-ssim on a frame too small for five scales: the reference fails in compute_ms_ssim ("scale below 1x1",
     # ms_ssim.c:172-177 -> combo error -> exception -> exit -1); here the same message, loudly, not a silent skip
     r, d = synth.make_clip(64, 48, 1, seed=1)
     synth.write_yuv(rp, r, "yuv420p")
     synth.write_yuv(dp, d, "yuv420p")
-    p = subprocess.run([OURS, "yuv420p", "64", "48", rp, dp, model, "--ms-ssim"], capture_output=True, text=True)
+    p = subprocess.run([OURS, "yuv420p", "64", "48", rp, dp, model, "--ms-ssim"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 255 and "scale below 1x1" in p.stderr
 
 
@@ -171,9 +171,14 @@ def test_fifo_inputs_and_reader_thread_settings_give_the_same_log(tmp_path):
     # the feeders open the FIFOs for writing in their own processes (that open blocks until vmafossexec opens the read end)
     feeders = [subprocess.Popen(["sh", "-c", 'exec cat "$0" > "$1"', src, dst]) for src, dst in ((rp, fr), (dp, fd))]
     log = str(tmp_path / "fifo.xml")
-    p = subprocess.run([OURS, case["fmt"], str(w), str(h), fr, fd, model, "--log", log], capture_output=True, text=True, timeout=120)
-    for f in feeders:
-        f.wait(timeout=30)
+    try:
+        p = subprocess.run([OURS, case["fmt"], str(w), str(h), fr, fd, model, "--log", log], capture_output=True, text=True, timeout=60)
+        for f in feeders:
+            f.wait(timeout=30)
+    finally:
+        for f in feeders:                                         # never leave a feeder blocked on its FIFO behind
+            if f.poll() is None:
+                f.kill()
     assert p.returncode == 0, p.stderr
     logs.append(re.sub(r'execFps="[^"]*"', "", open(log).read()))
     assert all(x == logs[0] for x in logs[1:])
@@ -189,7 +194,7 @@ def test_plain_c_caller_on_the_drop_in_boundary(tmp_path):
     libdir = os.path.join(ROOT, "vmaf_amd")
     cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
                          os.path.join(HERE, "c_caller", "c_caller.c"), "-o", exe, "-L", libdir, "-lvmaf_amd", f"-Wl,-rpath,{libdir}"],
-                        capture_output=True, text=True)
+                        capture_output=True, text=True, timeout=120)
     assert cc.returncode == 0, cc.stderr
     model = os.path.join(ROOT, case["model"])
     p = subprocess.run([exe, rp, dp, str(w), str(h), model], capture_output=True, text=True, timeout=120)
@@ -240,4 +245,4 @@ def test_feature_tool_speaks_the_reference_grammar(name, tmp_path):
         assert (gk, gf) == (wk, wf), (g, w_)
         assert abs(float(gv) - float(wv)) <= 1e-4 + 2e-6 * abs(float(wv)), (g, w_)
     # usage errors: exit 2 (vmaf_main.c:161-176)
-    assert subprocess.run([os.path.join(ROOT, "vmaf_amd", "vmaf"), "all"], capture_output=True).returncode == 2
+    assert subprocess.run([os.path.join(ROOT, "vmaf_amd", "vmaf"), "all"], capture_output=True, timeout=120).returncode == 2

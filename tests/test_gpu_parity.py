@@ -336,32 +336,36 @@ def test_two_async_calls_in_flight():
 
 def test_engines_on_concurrent_host_threads():
     """Engines are independent objects (own streams, buffers, pending slots; the error string is thread-local): four host
-    threads, each with its own engine and clip, running at the same time give bit for bit what they give alone."""
+    threads, each driving its own engine and clip at the same time, get bit for bit what the engines give alone.  Engines
+    are created and destroyed on the main thread; only the extract calls overlap (daemon threads, bounded joins: a stuck
+    thread fails the test instead of holding the process)."""
     import threading
     clips = [_clip(320 + 16 * k, 180 + 8 * k, 6, seed=40 + k) for k in range(4)]
-    alone = []
-    for ref, dis in clips:
-        with vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) as e:
-            alone.append(e.extract(ref, dis))
-    got, errs = [None] * 4, []
+    engines = [vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) for ref, _ in clips]
+    try:
+        alone = [e.extract(ref, dis) for e, (ref, dis) in zip(engines, clips)]
+        got, errs = [None] * 4, []
 
-    def work(k):
-        try:
-            ref, dis = clips[k]
-            with vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) as e:
+        def work(k):
+            try:
+                ref, dis = clips[k]
                 for _ in range(5):
-                    got[k] = e.extract(ref, dis)
-        except Exception as ex:                                   # noqa: BLE001 - reported below
-            errs.append(repr(ex))
+                    got[k] = engines[k].extract(ref, dis)
+            except Exception as ex:                               # noqa: BLE001 - reported below
+                errs.append(repr(ex))
 
-    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(timeout=60)
-    assert not errs, errs
-    for k in range(4):
-        assert np.array_equal(got[k], alone[k])
+        th = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=30)
+        assert not any(t.is_alive() for t in th), "an extract call did not return"
+        assert not errs, errs
+        for k in range(4):
+            assert np.array_equal(got[k], alone[k])
+    finally:
+        for e in engines:
+            e.close()
 
 
 @pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 101, 75), (10, 320, 180)])

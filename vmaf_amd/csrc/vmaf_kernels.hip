@@ -1014,9 +1014,22 @@ __global__ __launch_bounds__(256) void lpf_decimate_kernel(const float *__restri
     const float *img = (plane ? dis : ref) + (size_t)frame * src_frame_stride;
     float *out = (plane ? odis : oref) + (size_t)frame * sw * sh;
     const int x0 = blockIdx.x * LPF_TW, y0 = blockIdx.y * LPF_TH;
-    for (int idx = threadIdx.x; idx < LPF_IH * LPF_IW; idx += 256) {
-        const int ly = idx / LPF_IW, lx = idx - ly * LPF_IW;
-        tile[idx] = img[(size_t)sym_idx(2 * y0 - 4 + ly, h) * src_row_stride + sym_idx(2 * x0 - 4 + lx, w)];
+    {   // every global load of a thread is in flight before its first LDS write (one memory round trip per tile)
+        constexpr int N = LPF_IH * LPF_IW, IT = (N + 255) / 256;
+        float a[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < N) {
+                const int ly = idx / LPF_IW, lx = idx - ly * LPF_IW;
+                a[it] = img[(size_t)sym_idx(2 * y0 - 4 + ly, h) * src_row_stride + sym_idx(2 * x0 - 4 + lx, w)];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < N) tile[idx] = a[it];
+        }
     }
     __syncthreads();
     const int ox = threadIdx.x & 31, oy = threadIdx.x >> 5;
@@ -1063,11 +1076,28 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
     const int vw = w - 10, vh = h - 10;                              // valid output size
     const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
     const float *fr = ref + (size_t)blockIdx.z * w * h, *fc = cmp + (size_t)blockIdx.z * w * h;
-    for (int idx = tid; idx < SS_IH * SS_IW; idx += 256) {
-        const int ly = idx / SS_IW, lx = idx - ly * SS_IW;
-        const size_t g = (size_t)min(y0 + ly, h - 1) * w + min(x0 + lx, w - 1);   // clamped reads feed masked outputs only
-        rt[ly * SS_IP + lx] = fr[g];
-        ct[ly * SS_IP + lx] = fc[g];
+    {   // all global loads of a thread in flight before its first LDS write
+        constexpr int N = SS_IH * SS_IW, IT = (N + 255) / 256;
+        float a[IT], b[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < N) {
+                const int ly = idx / SS_IW, lx = idx - ly * SS_IW;
+                const size_t g = (size_t)min(y0 + ly, h - 1) * w + min(x0 + lx, w - 1);   // clamped reads feed masked outputs only
+                a[it] = fr[g];
+                b[it] = fc[g];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < N) {
+                const int ly = idx / SS_IW, lx = idx - ly * SS_IW;
+                rt[ly * SS_IP + lx] = a[it];
+                ct[ly * SS_IP + lx] = b[it];
+            }
+        }
     }
     __syncthreads();
     if (tid < SS_IH * (SS_TW / SS_SEG)) {
@@ -1150,11 +1180,27 @@ __global__ __launch_bounds__(256) void ansnr_kernel(const float *__restrict__ re
     __shared__ double red[8];
     const float *fr = ref + (size_t)blockIdx.z * frame_stride, *fd = dis + (size_t)blockIdx.z * frame_stride;
     const int x0 = blockIdx.x * AN_TW, y0 = blockIdx.y * AN_TH;
-    for (int idx = threadIdx.x; idx < AN_IH * AN_IW; idx += 256) {
-        const int ly = idx / AN_IW, lx = idx - ly * AN_IW;
-        const size_t g = (size_t)mirror_idx(y0 - 2 + ly, h) * row_stride + mirror_idx(x0 - 2 + lx, w);
-        tr[idx] = fr[g] + -128.0f;                                   // offset_image, ansnr.c:174-177 / all.c:128-129
-        td[idx] = fd[g] + -128.0f;
+    {   // all global loads of a thread in flight before its first LDS write
+        constexpr int N = AN_IH * AN_IW, IT = (N + 255) / 256;
+        float a[IT], b[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < N) {
+                const int ly = idx / AN_IW, lx = idx - ly * AN_IW;
+                const size_t g = (size_t)mirror_idx(y0 - 2 + ly, h) * row_stride + mirror_idx(x0 - 2 + lx, w);
+                a[it] = fr[g];
+                b[it] = fd[g];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < N) {
+                tr[idx] = a[it] + -128.0f;                           // offset_image, ansnr.c:174-177 / all.c:128-129
+                td[idx] = b[it] + -128.0f;
+            }
+        }
     }
     __syncthreads();
     double acc[2] = { 0.0, 0.0 };
