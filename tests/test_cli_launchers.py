@@ -22,9 +22,9 @@ def test_run_vmaf_usage_errors_exit_2():
     for args in ([], ["yuv420p", "64", "48", "a"], ["yuv420p", "x", "48", "a", "b"], ["nv12", "64", "48", "a", "b"],
                  ["yuv420p", "64", "48", "a", "b", "--out-fmt", "csv"], ["yuv420p", "64", "48", "a", "b", "--pool", "max"],
                  ["yuv420p", "-1", "48", "a", "b"]):
-        p = subprocess.run(RUN + args, capture_output=True, text=True, timeout=120)
+        p = subprocess.run(RUN + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 2, args
-    assert "usage: run_vmaf fmt width height ref_path dis_path" in subprocess.run(RUN, capture_output=True, text=True, timeout=120).stdout
+    assert "usage: run_vmaf fmt width height ref_path dis_path" in subprocess.run(RUN, capture_output=True, text=True, timeout=300).stdout
 
 
 def test_batch_file_grammar(tmp_path):
@@ -34,9 +34,9 @@ def test_batch_file_grammar(tmp_path):
     assert rc == 0 and [a.asset_id for a in assets] == [0, 1]
     assert assets[1].asset_dict == {"width": 64, "height": 48, "yuv_type": "yuv422p10le"}
     f.write_text("yuv420p 576 324 r0.yuv d0.yuv\nbogus 1 2 a b\n")
-    assert subprocess.run(BATCH + [str(f)], capture_output=True, text=True, timeout=120).returncode == 1
-    assert subprocess.run(BATCH, capture_output=True, text=True, timeout=120).returncode == 2
-    assert subprocess.run(BATCH + [str(f), "--out-fmt", "csv"], capture_output=True, text=True, timeout=120).returncode == 2
+    assert subprocess.run(BATCH + [str(f)], capture_output=True, text=True, timeout=300).returncode == 1
+    assert subprocess.run(BATCH, capture_output=True, text=True, timeout=300).returncode == 2
+    assert subprocess.run(BATCH + [str(f), "--out-fmt", "csv"], capture_output=True, text=True, timeout=300).returncode == 2
 
 
 def test_result_formats_follow_the_reference_schema():

@@ -109,7 +109,7 @@ def test_vmafossexec_meets_the_pinned_scores_of_the_model_and_flag_variants(tmp_
         phone = v["model"].startswith("model/")
         cmd = [os.path.join(root, "vmaf_amd", "vmafossexec"), "yuv420p", "1920", "1080", rp, dp, os.path.join(root, v["model"])]
         cmd += (["--phone-model"] if phone else ["--enable-transform"] if v["enable_transform"] else []) + (["--disable-clip"] if v["disable_clip"] else [])
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr + p.stdout
         got = float(re.search(r"VMAF score = ([-0-9.]+)", p.stdout).group(1))
         assert abs(got - v["vmaf"]) < 1e-4, (v, got)
