@@ -188,8 +188,16 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     const int slot = (e->pend_head + e->pend_count) % kDepth;
     if (e->timed) HIP_TRY(hipEventRecord(e->ev_t0[slot], e->s_main));
     HIP_TRY(hipEventRecord(e->ev_in, e->s_main));             // inputs (staging copies) are ready at this point
-    HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
-    HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
+    // When the ADM chain and the motion launch start.  In the reference's orders the scale-0 VIF launch saturates the
+    // VALUs on its own, so they start after it and share the GPU with VIF scales 1-3, which are too small to fill it
+    // (+1.4 % throughput, and the dominant kernel runs undisturbed).  In the fused order that launch is 35 % shorter and
+    // leaves issue slots: there they start at once (+2 %).  Measured with bench.py, both ways, both orders.
+    static const int sched_env = getenv("VMAF_HIP_ADM_START") ? atoi(getenv("VMAF_HIP_ADM_START")) : -1;   // 0 late, 1 at once
+    const bool adm_early = sched_env >= 0 ? sched_env != 0 : e->order == 2;
+    if (adm_early) {
+        HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
+        HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
+    }
 
     // ---- optional metrics on their own stream (combo.c:168-230: before the -128 offset, i.e. on the planes as given)
     if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) {
@@ -236,6 +244,11 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
         HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc],
                                    nr, nd, nfs, nrs, e->s_main));
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1[slot], e->s_main));
+        if (sc == 0 && !adm_early) {
+            HIP_TRY(hipEventRecord(e->ev_in, e->s_main));
+            HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
+            HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
+        }
         cr = nr; cd = nd; cfs = nfs; crs = nrs;
     }
 
