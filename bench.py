@@ -117,11 +117,16 @@ def main():
     ap.add_argument("--order", choices=["avx", "scalar", "fma"], default="avx",
                     help="summation order of the convolutions: the reference's AVX order (default, bit-exact), its scalar order, "
                          "or fused multiply-adds (fast mode, within tolerance but not bit-exact; not the headline workload)")
+    ap.add_argument("--repeat", type=int, default=0,
+                    help="how many times the distinct synthetic frames are tiled into one batch (default: the workload's own, "
+                         "4 at 1080p = 120 frames per step; 1 = 30 frames per step)")
     ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
     args = ap.parse_args()
 
     global W, H, BITS, FRAMES_PER_STEP
     W, H, BITS, DISTINCT, REPEAT = WORKLOADS[args.workload]
+    if args.repeat > 0:
+        REPEAT = args.repeat
     FRAMES_PER_STEP = DISTINCT * REPEAT
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
