@@ -57,13 +57,24 @@ double compute_vmaf_raw(char* fmt, int width, int height, int (*read_frame_raw)(
 int compute_vmaf_raw_noexcept(double *score, char* fmt, int width, int height, int (*read_frame_raw)(void *ref_luma, void *main_luma, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len);
 
 /*
+ * The feature names of a model in model order (model_dict['feature_names'], wrapper/src/vmaf.cpp:79-81), e.g.
+ * "VMAF_feature_adm2_score": *n_features = their number D; names_out (may be NULL) receives them separated by '\n',
+ * NUL-terminated, when names_len is large enough (otherwise the call fails and *n_features still holds D).
+ * Returns 0 on success.
+ */
+int vmaf_amd_model_feature_names(const char *model_path, int *n_features, char *names_out, int names_len,
+                                 char *errbuf, int errbuf_len);
+
+/*
  * Fusion half only (wrapper/src/vmaf.cpp:351-559): atoms [nframes][20] (layout in vmaf_hip.h) ->
  * per-frame VMAF scores and the derived feature vectors named by the model, in model order
- * (features_out: [nframes][n_features], may be NULL).  The SVR runs on `device`.  Returns 0 on success.
+ * (features_out: [nframes][features_capacity], may be NULL; the first D columns of a row are written, D =
+ * vmaf_amd_model_feature_names' n_features; features_capacity < D is an error, nothing is written).
+ * The SVR runs on `device`.  Returns 0 on success.
  */
 int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip,
                                 int enable_transform, int device, double *vmaf_out, double *features_out,
-                                char *errbuf, int errbuf_len);
+                                int features_capacity, char *errbuf, int errbuf_len);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -14,6 +14,19 @@
  * Error convention: functions return 0 on success, non-zero on failure (the convention of the
  * reference's C feature functions, combo.c:240-243); vmaf_hip_last_error() gives the message.
  * Nothing here falls back to a CPU path: without a usable HIP device every call fails.
+ *
+ * Threading contract (the reference's compute_vmaf is single-threaded and not re-entrant: it writes the process-global
+ * `cpu`, libvmaf.cpp:56-61, and libsvm's static line buffer, svm.cpp:330-331; this library has no such globals):
+ *   - An engine is NOT internally locked: at most one thread may be inside a call on a given engine at a time (calls on
+ *     one engine from several threads need the caller's own mutex).  The thread may change from call to call.
+ *   - Different engines are independent - own streams, device buffers, pending slots - and may be created, used and
+ *     destroyed concurrently from different threads, on the same or on different devices
+ *     (tests/test_gpu_parity.py::test_engines_on_concurrent_host_threads).  vmaf_hip_engine_destroy waits for the whole
+ *     device to go idle, so it may stall (never corrupt) other engines' calls on that device.
+ *   - vmaf_hip_last_error() is per calling thread.  vmaf_hip_svm_predict, vmaf_hip_host_alloc/free and
+ *     vmaf_hip_device_count keep no state and may be called from any thread at any time.
+ *   - Every call makes the engine's device current on the calling thread (hipSetDevice) and leaves it so.
+ * Debug / profiling hooks live in include/vmaf_hip_debug.h.
  */
 #ifndef VMAF_HIP_H_
 #define VMAF_HIP_H_
@@ -165,23 +178,6 @@ int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes);
  */
 int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n_sv, int dim,
                          double gamma, double rho, const double *x, int n, double *out);
-
-/*
- * Stage-level test hook, the counterpart of the reference's *_OPT_DEBUG_DUMP paths (feature/src/vif.c:227-263,
- * adm.c:147-228): copies one intermediate plane of the LAST synchronised extract call to the host.
- * kind 0 / 1 = the ref / dis plane compute_vif works on at scale `level` (vif.c:157-186: blurred + decimated),
- * kind 2 / 3 = the ref / dis LL band compute_adm hands to scale `level` (adm.c:241-247); level 1..3; frame = index in
- * the batch.  The planes of the other stages never exist in memory here (they live in LDS / registers).
- */
-int vmaf_hip_engine_debug_read_plane(vmaf_hip_engine *e, int kind, int level, int frame, float *out, size_t out_floats,
-                                     int *width, int *height);
-
-/*
- * Kernel-level timing hook for bench.py: HIP-event time in milliseconds of the LAST extract call's
- * kernels, measured on the engine's own stream.  which: 0 = whole batch, 1 = VIF scale-0 statistic
- * kernel (the dominant kernel).  Returns < 0 when nothing has run.
- */
-double vmaf_hip_last_kernel_ms(vmaf_hip_engine *e, int which);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -24,11 +24,11 @@ def declared_functions(header):
     return sorted(names)
 
 
-@pytest.mark.parametrize("header", ["vmaf_hip.h", "libvmaf.h"])
+@pytest.mark.parametrize("header", ["vmaf_hip.h", "vmaf_hip_debug.h", "libvmaf.h"])
 def test_every_declared_symbol_is_exported(header):
     lib = ctypes.CDLL(vmaf_amd.library_path())
     names = declared_functions(header)
-    assert len(names) >= 3
+    assert len(names) >= 2
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
 
@@ -38,13 +38,13 @@ def test_nothing_else_is_exported():
     kernel launchers or C++ internals (the __hip_cuid_* markers come from the HIP toolchain)."""
     out = subprocess.run(["nm", "-D", "--defined-only", vmaf_amd.library_path()], capture_output=True, text=True, check=True, timeout=300).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[1] in "TDB"}
-    declared = set(declared_functions("vmaf_hip.h")) | set(declared_functions("libvmaf.h"))
+    declared = set(declared_functions("vmaf_hip.h")) | set(declared_functions("vmaf_hip_debug.h")) | set(declared_functions("libvmaf.h"))
     extra = {n for n in exported - declared if not n.startswith("__hip_cuid_")}
     assert not extra, sorted(extra)
 
 
 def test_headers_compile_as_c():
-    for header in ("vmaf_hip.h", "libvmaf.h"):
+    for header in ("vmaf_hip.h", "vmaf_hip_debug.h", "libvmaf.h"):
         src = f'#include "{header}"\nint main(void) {{ return 0; }}\n'
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-fsyntax-only"],
                        input=src.encode(), check=True, timeout=300)
@@ -82,10 +82,18 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
+def test_built_artefacts_are_present_and_fresh():
+    """The library and the two executables are build products, not tracked files: the tests must never run a stale one.
+    `make -q` answers whether anything is older than its sources."""
+    for name in ("libvmaf_amd.so", "vmafossexec", "vmaf"):
+        assert os.path.exists(os.path.join(ROOT, "vmaf_amd", name)), f"vmaf_amd/{name} is missing: run `make -C vmaf_amd/csrc` (or __graft_entry__.build())"
+    q = subprocess.run(["make", "-q", "-C", os.path.join(ROOT, "vmaf_amd", "csrc"), "all"], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, "vmaf_amd/csrc has changed since the last build: run `make -C vmaf_amd/csrc`"
+
+
 def test_vmafossexec_usage_and_exit_codes():
     exe = os.path.join(ROOT, "vmaf_amd", "vmafossexec")
-    if not os.path.exists(exe):
-        pytest.skip("vmafossexec not built")
+    assert os.path.exists(exe), "vmaf_amd/vmafossexec is missing: run `make -C vmaf_amd/csrc`"
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 255 and "Usage:" in p.stderr                     # main.cpp:148-152 returns -1
     p = subprocess.run([exe, "yuv420p", "0", "10", "a", "b", "m"], capture_output=True, text=True, timeout=300)

@@ -56,8 +56,65 @@ def test_result_formats_follow_the_reference_schema():
     assert abs(r.aggregate("VMAF_scores") - (1.0 / np.mean(1.0 / (np.array([70.0, 80.0]) + 1.0)) - 1.0)) < 1e-12
     r.set_pool("perc10")
     assert r.aggregate("VMAF_scores") == np.percentile([70.0, 80.0], 10)
-    xml = r.to_xml()
-    assert '<result executorId="VMAF_VF0.2.4b-0.6.1">' in xml and '<aggregate ' in xml and 'method="perc10"' in xml
+    xml = r.to_xml().splitlines()
+    assert xml[1] == '<result executorId="VMAF_VF0.2.4b-0.6.1">'
+    # Python 2's str(float) and attribute order: whole numbers keep '.0', frameNum / method come last
+    assert xml[4] == '    <frame VMAF_feature_adm2_score="0.9" VMAF_feature_motion2_score="0.0" VMAF_score="70.0" frameNum="0"/>'
+    assert xml[7] == '  <aggregate VMAF_feature_adm2_score="0.905" VMAF_feature_motion2_score="0.35" VMAF_score="71.0" method="perc10"/>'
+
+
+def test_result_matches_the_reference_held_golden():
+    """python/test/result_test.py:148-200: ResultFormattingTest loads python/test/resource/ssim_result_for_test.txt and
+    pins to_xml() as a string and to_dict() as a value.  The same values (tests/golden/result_fixture.json) through
+    cli.Result must give the same bytes."""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "result_fixture.json")))
+    a = fx["asset"]
+    asset = cli.Asset(a["dataset"], a["content_id"], a["asset_id"], a["ref_path"], a["dis_path"], a["width"], a["height"], "yuv420p")
+    r = cli.Result(asset, fx["scores"], executor_id=fx["executor_id"])
+    assert r.to_xml().strip() == "\n".join(fx["xml"])
+    assert r.to_dict() == fx["dict"]
+    assert list(r.to_dict()["frames"][0].keys())[0] == "frameNum" and list(r.to_dict()["aggregate"].keys())[-1] == "method"
+    text = r.to_json()
+    assert json.loads(text) == fx["dict"]
+    for line in fx["json_aggregate_lines"]:                   # aggregates with numpy.float64's 17 digits, as Python 2 printed them
+        assert line in text.split("\n")
+    assert cli.py2_str_float(100.0) == "100.0" and cli.py2_str_float(1e-5) == "1e-05" and cli.py2_str_float(76.69927127248) == "76.6992712725"
+    assert cli.py2_str_float(float("inf")) == "inf" and cli.py2_str_float(float("nan")) == "nan"
+
+
+def _fake_worker(kind, idx, q):
+    if kind == "ok":
+        q.put((idx, {"VMAF_scores": [1.0 + idx]}))
+        q.put(None)
+    elif kind == "raises":
+        q.put(("error", idx, "VmafHipError: short file"))
+        q.put(None)
+    elif kind == "dies":
+        os._exit(3)                                           # no sentinel, no message: the OOM killer, a GPU fault
+
+
+@pytest.mark.parametrize("kinds,want", [(("ok", "ok"), None), (("ok", "raises"), "asset 1 (r1 vs d1): VmafHipError: short file"),
+                                        (("dies", "ok"), "ended with exit code 3")])
+def test_batch_parent_never_waits_on_a_dead_worker(kinds, want):
+    """run_vmaf_in_batch --parallelize (cli._collect_from_workers): a worker that fails or dies before posting its
+    sentinel ends the run with a message, within the poll interval, instead of leaving the parent in q.get() forever."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    assets = [cli.Asset("cmd", 0, i, f"r{i}", f"d{i}", 64, 48, "yuv420p") for i in range(len(kinds))]
+    results = [None] * len(kinds)
+    procs = [ctx.Process(target=_fake_worker, args=(k, i, q)) for i, k in enumerate(kinds)]
+    for p in procs:
+        p.start()
+    t0 = time.time()
+    failure = cli._collect_from_workers(procs, q, assets, results, poll_s=0.2)
+    assert time.time() - t0 < 60
+    assert all(not p.is_alive() for p in procs)
+    if want is None:
+        assert failure is None and [r.scores["VMAF_scores"][0] for r in results] == [1.0, 2.0]
+    else:
+        assert failure is not None and want in failure
 
 
 def test_read_luma_formats(tmp_path):
@@ -108,9 +165,12 @@ def test_run_vmaf_in_batch_text_output(tmp_path):
     r1, d1, w1, h1 = _clip_files(tmp_path, c1["clip"], c1["fmt"], "1")
     f = tmp_path / "batch.txt"
     f.write_text(f"# two pairs\n{c0['fmt']} {w0} {h0} {r0} {d0}\n\n{c1['fmt']} {w1} {h1} {r1} {d1}\n")
-    for extra in ([], ["--parallelize"]):
-        p = subprocess.run(BATCH + [str(f)] + extra, capture_output=True, text=True, timeout=300)
+    outputs = []
+    # --parallelize with VMAF_HIP_DEVICES=0,0: two worker processes (spawned, one per listed device) on the one GPU
+    for extra, env in (([], {}), (["--parallelize"], {"VMAF_HIP_DEVICES": "0,0"})):
+        p = subprocess.run(BATCH + [str(f)] + extra, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr
+        outputs.append(p.stdout)
         blocks = p.stdout.split("============================\nAsset ")
         assert len(blocks) == 3 and blocks[1].startswith("0:\n") and blocks[2].startswith("1:\n")
         for blk, case in ((blocks[1], c0), (blocks[2], c1)):
@@ -122,3 +182,38 @@ def test_run_vmaf_in_batch_text_output(tmp_path):
                 assert abs(float(vals["VMAF_feature_adm2_score"]) - want["adm2"]) < 1e-4
             agg = re.search(r"^Aggregate \(mean\): .*VMAF_score:([0-9.]+)$", blk, flags=re.M)
             assert agg and abs(float(agg.group(1)) - np.mean([fr["vmaf"] for fr in case["frames"]])) < 1e-3
+    assert outputs[0] == outputs[1]                             # worker processes change nothing in the output
+    # a pair that cannot be scored (short file) under --parallelize: exit 1 with the asset named, no hang
+    bad = tmp_path / "short.yuv"
+    bad.write_bytes(b"\0" * 100)
+    f.write_text(f"{c0['fmt']} {w0} {h0} {r0} {d0}\n{c1['fmt']} {w1} {h1} {bad} {bad}\n")
+    p = subprocess.run(BATCH + [str(f), "--parallelize"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, VMAF_HIP_DEVICES="0,0"))
+    assert p.returncode == 1 and "asset 1" in p.stderr, (p.returncode, p.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_run_vmaf_xml_is_what_python2_printed(tmp_path):
+    """run_vmaf --out-fmt xml (result.py:178-224 under Python 2, pinned by python/test/result_test.py:148-160):
+    attributes in plain string order - the VMAF_* scores, then frameNum / method - and values through str(float)."""
+    case = GOLD["default"]
+    rp, dp, w, h = _clip_files(tmp_path, case["clip"], case["fmt"])
+    p = subprocess.run(RUN + [case["fmt"], str(w), str(h), rp, dp, "--out-fmt", "xml", "--pool", "harmonic_mean"],
+                       capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert lines[0] == '<?xml version="1.0" ?>' and lines[1] == '<result executorId="VMAF_VF0.2.4b-0.6.1">'
+    names = ["VMAF_feature_adm2_score", "VMAF_feature_motion2_score"] + [f"VMAF_feature_vif_scale{s}_score" for s in range(4)] + ["VMAF_score"]
+    frames = [l for l in lines if l.strip().startswith("<frame ")]
+    assert len(frames) == len(case["frames"])
+    for i, (l, want) in enumerate(zip(frames, case["frames"])):
+        attrs = re.findall(r'(\w+)="([^"]*)"', l)
+        assert [a for a, _ in attrs] == names + ["frameNum"] and attrs[-1][1] == str(i)
+        vals = dict(attrs)
+        assert abs(float(vals["VMAF_score"]) - want["vmaf"]) < 1e-3
+        for a, v in attrs[:-1]:
+            assert v == cli.py2_str_float(float(v)) and len(v.replace(".", "").replace("-", "").lstrip("0")) <= 12
+    agg = [l for l in lines if l.strip().startswith("<aggregate ")]
+    assert len(agg) == 1
+    attrs = re.findall(r'(\w+)="([^"]*)"', agg[0])
+    assert [a for a, _ in attrs] == names + ["method"] and attrs[-1][1] == "harmonic_mean"

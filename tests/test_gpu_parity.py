@@ -46,7 +46,7 @@ ORDERS = {"avx": oracle.ORDER_AVX, "scalar": oracle.ORDER_SCALAR}
 
 @pytest.mark.parametrize("order", ["avx", "scalar"])
 @pytest.mark.parametrize("w,h,frames", [(64, 48, 5), (577, 325, 3), (576, 324, 3), (200, 32, 2), (33, 130, 2), (100, 75, 2),
-                                        (1920, 1080, 2)])
+                                        (1280, 720, 2), (1920, 1080, 2)])
 def test_atoms_match_oracle(w, h, frames, order):
     """Both summation orders of the reference (AVX kernels = its default on x86, scalar loops = disable_avx)."""
     ref, dis = _clip(w, h, frames, seed=w + h)
@@ -334,38 +334,91 @@ def test_two_async_calls_in_flight():
         assert np.array_equal(got.reshape(6, 20), want)
 
 
+@pytest.mark.parametrize("kind", ["u8", "u16", "f32"])
+def test_host_calls_in_flight_overlap_copy_and_compute(kind):
+    """Host-pointer calls: the H2D copies of call k+1 go to their own stream and staging set while call k computes
+    (vmaf_engine.cpp: s_copy, raw_ref[slot] / stage_ref[slot]).  Two calls in flight from page-locked memory, batch
+    after batch, must give bit for bit what the synchronous calls give - for raw 8-bit, raw 16-bit and fp32 planes,
+    with a short last batch and a scene cut at a batch edge."""
+    from vmaf_amd.binding import PinnedArray
+    bits = 10 if kind == "u16" else 8
+    w, h, F, B = 320, 180, 11, 3
+    r, d = synth.make_clip(w, h, F, bits=bits, seed=77, cuts=(6,))
+    if kind == "f32":
+        r, d = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    with vmaf_amd.Engine(w, h, max_batch=B) as e:
+        want = e.extract(r, d) if kind == "f32" else e.extract_raw(r, d)
+    pr, pd = PinnedArray(r.shape, r.dtype), PinnedArray(d.shape, d.dtype)
+    try:
+        pr.array[...] = r
+        pd.array[...] = d
+        got = np.zeros((F, 20))
+        with vmaf_amd.Engine(w, h, max_batch=B) as e:
+            inflight = 0
+            for s0 in range(0, F, B):
+                n = min(B, F - s0)
+                if inflight == 2:
+                    e.sync_oldest()
+                    inflight -= 1
+                e.extract_host_async(pr.array[s0:s0 + n], pd.array[s0:s0 + n], got[s0:s0 + n], continue_sequence=s0 > 0)
+                inflight += 1
+            e.sync()
+            assert np.array_equal(got, want)
+            # pageable memory (the copies degrade to synchronous ones) and a second pass over the same engine
+            got2 = np.zeros((F, 20))
+            for s0 in range(0, F, B):
+                n = min(B, F - s0)
+                e.extract_host_async(r[s0:s0 + n], d[s0:s0 + n], got2[s0:s0 + n], continue_sequence=s0 > 0)
+                if s0:
+                    e.sync_oldest()
+            e.sync()
+            assert np.array_equal(got2, want)
+    finally:
+        pr.close()
+        pd.close()
+
+
 def test_engines_on_concurrent_host_threads():
-    """Engines are independent objects (own streams, buffers, pending slots; the error string is thread-local): four host
-    threads, each driving its own engine and clip at the same time, get bit for bit what the engines give alone.  Engines
-    are created and destroyed on the main thread; only the extract calls overlap (daemon threads, bounded joins: a stuck
-    thread fails the test instead of holding the process)."""
+    """include/vmaf_hip.h, threading contract: engines are independent objects (own streams, buffers, pending slots; the
+    error string is thread-local) and may be created, used and destroyed concurrently.  Four host threads each create
+    their own engine, score their own clip five times (sync, raw and pipelined host calls) and destroy the engine, all at
+    the same time; every thread gets bit for bit what an engine gives alone.  Daemon threads with bounded joins: a stuck
+    thread fails the test instead of holding the process."""
     import threading
     clips = [_clip(320 + 16 * k, 180 + 8 * k, 6, seed=40 + k) for k in range(4)]
-    engines = [vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) for ref, _ in clips]
-    try:
-        alone = [e.extract(ref, dis) for e, (ref, dis) in zip(engines, clips)]
-        got, errs = [None] * 4, []
+    alone = []
+    for ref, dis in clips:
+        with vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) as e:
+            alone.append(e.extract(ref, dis))
+    got, errs = [None] * 4, []
 
-        def work(k):
-            try:
-                ref, dis = clips[k]
-                for _ in range(5):
-                    got[k] = engines[k].extract(ref, dis)
-            except Exception as ex:                               # noqa: BLE001 - reported below
-                errs.append(repr(ex))
+    def work(k):
+        try:
+            ref, dis = clips[k]
+            for it in range(5):
+                with vmaf_amd.Engine(ref.shape[2], ref.shape[1], max_batch=3) as e:
+                    if it % 2:
+                        out = np.zeros((6, 20))
+                        e.extract_host_async(ref[:3], dis[:3], out[:3])
+                        e.extract_host_async(ref[3:], dis[3:], out[3:], continue_sequence=True)
+                        e.sync()
+                        got[k] = out
+                    else:
+                        got[k] = e.extract(ref, dis)
+                if not np.array_equal(got[k], alone[k]):
+                    errs.append(f"thread {k} iteration {it}: results differ")
+        except Exception as ex:                               # noqa: BLE001 - reported below
+            errs.append(repr(ex))
 
-        th = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(4)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join(timeout=30)
-        assert not any(t.is_alive() for t in th), "an extract call did not return"
-        assert not errs, errs
-        for k in range(4):
-            assert np.array_equal(got[k], alone[k])
-    finally:
-        for e in engines:
-            e.close()
+    th = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in th), "a call did not return"
+    assert not errs, errs
+    for k in range(4):
+        assert np.array_equal(got[k], alone[k])
 
 
 @pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 101, 75), (10, 320, 180)])

@@ -9,7 +9,7 @@ There is no CPU fallback: importing works anywhere, but every compute call raise
 the library or a HIP device is missing.
 """
 from .binding import (ATOM_NAMES, Engine, VmafHipError, compute_vmaf_from_arrays, device_count, load_library,  # noqa: F401
-                      predict_from_atoms, svm_predict, library_path)
+                      model_feature_names, predict_from_atoms, svm_predict, library_path)
 
 __all__ = ["ATOM_NAMES", "Engine", "VmafHipError", "compute_vmaf_from_arrays", "device_count", "load_library",
-           "predict_from_atoms", "svm_predict", "library_path"]
+           "model_feature_names", "predict_from_atoms", "svm_predict", "library_path"]

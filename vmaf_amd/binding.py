@@ -75,7 +75,8 @@ def load_library():
     L.vmaf_hip_last_kernel_ms.restype = C.c_double
     L.compute_vmaf_noexcept.argtypes = [_dp, C.c_char_p, i, i, READ_FRAME, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                         i, i, i, i, i, i, i, C.c_char_p, C.c_char_p, i]
-    L.vmaf_amd_predict_from_atoms.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, C.c_char_p, i]
+    L.vmaf_amd_predict_from_atoms.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, i, C.c_char_p, i]
+    L.vmaf_amd_model_feature_names.argtypes = [C.c_char_p, C.POINTER(i), C.c_char_p, i, C.c_char_p, i]
     _lib = L
     return L
 
@@ -213,6 +214,28 @@ class Engine:
         self._keep = ([self._keep[-1]] if self._keep else []) + [(d_ref, d_dis, out)]   # buffers of the calls in flight
         return out
 
+    def extract_host_async(self, ref, dis, out, continue_sequence=False):
+        """One asynchronous call (at most two in flight) on host arrays [n,h,w]: float32 (the read_frame contract) or
+        uint8 / uint16 raw luma.  The arrays and `out` [n,20] must stay alive and untouched until the call is
+        synchronised (sync_oldest / sync); page-locked memory (host_alloc_array) makes the copies truly asynchronous."""
+        n, h, w = ref.shape
+        if (h, w) != (self.h, self.w) or dis.shape != ref.shape or ref.dtype != dis.dtype:
+            raise VmafHipError(f"shape {ref.shape}/{dis.shape} does not match engine {self.h}x{self.w}")
+        if not (ref.flags.c_contiguous and dis.flags.c_contiguous and out.flags.c_contiguous):
+            raise VmafHipError("contiguous arrays needed")
+        b = ref.dtype.itemsize
+        if ref.dtype == np.float32:
+            rc = self.L.vmaf_hip_extract_host_async(self._h, ref.ctypes.data, dis.ctypes.data, w * 4, w * h * 4, n,
+                                                    1 if continue_sequence else 0, out.ctypes.data_as(_dp))
+        elif ref.dtype in (np.uint8, np.uint16):
+            rc = self.L.vmaf_hip_extract_host_raw_async(self._h, ref.ctypes.data, dis.ctypes.data, b, w * b, w * h * b, n,
+                                                        1 if continue_sequence else 0, out.ctypes.data_as(_dp))
+        else:
+            raise VmafHipError(f"dtype {ref.dtype} is none of float32, uint8, uint16")
+        if rc:
+            raise VmafHipError(_err(self.L))
+        self._keep = ([self._keep[-1]] if self._keep else []) + [(ref, dis, out)]
+
     def sync(self):
         if self.L.vmaf_hip_engine_sync(self._h):
             raise VmafHipError(_err(self.L))
@@ -252,6 +275,26 @@ class Engine:
         return self.L.vmaf_hip_last_kernel_ms(self._h, which)
 
 
+class PinnedArray:
+    """A numpy array in page-locked host memory (vmaf_hip_host_alloc): H2D copies from it are asynchronous."""
+
+    def __init__(self, shape, dtype):
+        self.L = load_library()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = self.L.vmaf_hip_host_alloc(max(n, 1))
+        if not self._p:
+            raise VmafHipError(_err(self.L))
+        self.array = np.ctypeslib.as_array((C.c_ubyte * n).from_address(self._p)).view(dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self.L.vmaf_hip_host_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+
 def svm_predict(sv, coef, gamma, rho, x, device=0):
     L = load_library()
     sv = np.ascontiguousarray(sv, np.float64)
@@ -264,17 +307,30 @@ def svm_predict(sv, coef, gamma, rho, x, device=0):
     return out
 
 
-def predict_from_atoms(atoms, model_path=DEFAULT_MODEL, disable_clip=False, enable_transform=False, device=0,
-                       n_features=6):
-    """atoms [F,20] -> (vmaf [F], features [F,n_features] in the model's feature order)."""
+def model_feature_names(model_path=DEFAULT_MODEL):
+    """The model's feature names ("VMAF_feature_adm2_score", ...) in model order, as the library's loader reads them."""
+    L = load_library()
+    n = C.c_int()
+    names = C.create_string_buffer(1 << 16)
+    err = C.create_string_buffer(1024)
+    if L.vmaf_amd_model_feature_names(model_path.encode(), C.byref(n), names, len(names), err, 1024):
+        raise VmafHipError(err.value.decode(errors="replace"))
+    out = names.value.decode().split("\n") if n.value else []
+    assert len(out) == n.value
+    return out
+
+
+def predict_from_atoms(atoms, model_path=DEFAULT_MODEL, disable_clip=False, enable_transform=False, device=0):
+    """atoms [F,20] -> (vmaf [F], features [F,D] in the model's feature order; D from the library)."""
     L = load_library()
     atoms = np.ascontiguousarray(atoms, np.float64)
     F = len(atoms)
+    D = len(model_feature_names(model_path))
     vm = np.zeros(F)
-    feats = np.zeros((F, n_features))
+    feats = np.zeros((F, D))
     err = C.create_string_buffer(1024)
     if L.vmaf_amd_predict_from_atoms(model_path.encode(), atoms.ctypes.data_as(_dp), F, int(disable_clip),
-                                     int(enable_transform), device, vm.ctypes.data_as(_dp), feats.ctypes.data_as(_dp),
+                                     int(enable_transform), device, vm.ctypes.data_as(_dp), feats.ctypes.data_as(_dp), D,
                                      err, 1024):
         raise VmafHipError(err.value.decode(errors="replace"))
     return vm, feats

@@ -60,6 +60,22 @@ POOL_FUNCS = {None: np.mean, 'mean': np.mean, 'harmonic_mean': harmonic_mean, 'm
 POOL_NAMES = {np.mean: 'mean', np.min: 'amin', np.median: 'median'}      # numpy's __name__ of the era ('amin' for np.min)
 
 
+def py2_str_float(v):
+    """str(float) of Python 2 (and of numpy.float64 then): 12 significant digits, '.0' kept on whole numbers."""
+    s = '%.12g' % float(v)
+    if not any(c in s for c in '.en'):                # no point, exponent, inf or nan
+        s += '.0'
+    return s
+
+
+def py2_repr_float64(v):
+    """repr(numpy.float64) of the reference's era, which is what its json.dumps printed aggregates with."""
+    s = '%.17g' % float(v)
+    if not any(c in s for c in '.en'):
+        s += '.0'
+    return s
+
+
 class Asset:
     def __init__(self, dataset, content_id, asset_id, ref_path, dis_path, width, height, yuv_type):
         self.dataset, self.content_id, self.asset_id = dataset, content_id, asset_id
@@ -81,8 +97,9 @@ class Asset:
 class Result:
     """result.py:55-293 for the VMAF runner: per-frame lists keyed '<X>_scores', aggregates '<X>_score'."""
 
-    def __init__(self, asset, scores):
+    def __init__(self, asset, scores, executor_id=EXECUTOR_ID):
         self.asset, self.scores = asset, scores                      # scores: dict '<X>_scores' -> list
+        self.executor_id = executor_id
         self.method = np.mean
 
     def set_pool(self, name):
@@ -100,7 +117,7 @@ class Result:
 
     def to_string(self):
         ks = self.keys()
-        s = f"Asset: {self.asset.to_full_repr()}\nExecutor: {EXECUTOR_ID}\nResult:\n"
+        s = f"Asset: {self.asset.to_full_repr()}\nExecutor: {self.executor_id}\nResult:\n"
         n = len(self.scores[ks[0]])
         for i in range(n):
             s += f"Frame {i}: " + ", ".join(f"{k[:-1]}:{self.scores[k][i]:.6f}" for k in ks) + "\n"
@@ -110,7 +127,7 @@ class Result:
     def to_dict(self):
         ks = self.keys()
         top = OrderedDict()
-        top['executorId'] = EXECUTOR_ID
+        top['executorId'] = self.executor_id
         top['asset'] = {'identifier': str(self.asset)}
         top['frames'] = []
         for i in range(len(self.scores[ks[0]])):
@@ -123,25 +140,44 @@ class Result:
         return top
 
     def to_json(self):
-        return json.dumps(self.to_dict(), sort_keys=False, indent=4)
+        """result.py:289-293.  Python 2's json printed every float with repr(): the per-frame scores (Python floats) in
+        their shortest form, the aggregates (numpy.float64 from the pooling function) with numpy's 17 significant digits
+        of the era - "VMAF_score": 65.44885887590759 per frame, "VMAF_score": 0.93335333333333337 in the aggregate
+        (README.md:131-140, python/test/result_test.py:192-197).  Both parse to the same doubles."""
+        d = self.to_dict()
+        marks = {}
+        for k, v in list(d['aggregate'].items()):
+            if isinstance(v, float):
+                mark = "@@AGG%d@@" % len(marks)
+                marks['"%s"' % mark] = py2_repr_float64(v)
+                d['aggregate'][k] = mark
+        text = json.dumps(d, sort_keys=False, indent=4, separators=(', ', ': '))   # Python 2.7 kept ', ' before the line break
+        for mark, num in marks.items():
+            text = text.replace(mark, num)
+        return text
 
     def to_xml(self):
+        """result.py:178-224 as Python 2 printed it: values through str() (12 significant digits), attributes in plain
+        string order, which puts frameNum and method last (python/test/result_test.py:148-160 pins both)."""
         from xml.dom import minidom
         from xml.etree import ElementTree
         ks = self.keys()
+
+        def set_sorted(elem, attrs):
+            for name in sorted(attrs):
+                elem.set(name, attrs[name])
+
         top = ElementTree.Element('result')
-        top.set('executorId', EXECUTOR_ID)
+        top.set('executorId', self.executor_id)
         ElementTree.SubElement(top, 'asset').set('identifier', str(self.asset))
         frames = ElementTree.SubElement(top, 'frames')
         for i in range(len(self.scores[ks[0]])):
-            fr = ElementTree.SubElement(frames, 'frame')
-            fr.set('frameNum', str(i))
-            for k in ks:
-                fr.set(k[:-1], repr(float(self.scores[k][i])))
-        agg = ElementTree.SubElement(top, 'aggregate')
-        agg.set('method', self.method_name)
-        for k in ks:
-            agg.set(k[:-1], repr(self.aggregate(k)))
+            attrs = {k[:-1]: py2_str_float(self.scores[k][i]) for k in ks}
+            attrs['frameNum'] = str(i)
+            set_sorted(ElementTree.SubElement(frames, 'frame'), attrs)
+        attrs = {k[:-1]: py2_str_float(self.aggregate(k)) for k in ks}
+        attrs['method'] = self.method_name
+        set_sorted(ElementTree.SubElement(top, 'aggregate'), attrs)
         return minidom.parseString(ElementTree.tostring(top, 'utf-8')).toprettyxml(indent="  ")
 
 
@@ -219,22 +255,11 @@ def score_asset(asset, model_path, phone_model, device=0, engine_cache=None, lum
             engine_cache[key] = eng
     atoms = eng.extract_raw(ref[:frames], dis[:frames])
     model_path = model_path or binding.DEFAULT_MODEL
-    names = _model_feature_names(model_path)
-    vm, feats = binding.predict_from_atoms(atoms, model_path, enable_transform=phone_model, device=device,
-                                           n_features=len(names))
+    names = binding.model_feature_names(model_path)
+    vm, feats = binding.predict_from_atoms(atoms, model_path, enable_transform=phone_model, device=device)
     scores = {name + 's': feats[:, j].tolist() for j, name in enumerate(names)}
     scores['VMAF_scores'] = vm.tolist()
     return Result(asset, scores)
-
-
-def _model_feature_names(model_path):
-    text = open(model_path).read()
-    seen = []
-    for m in re.finditer(r"S'(VMAF_feature_\w+_score)'", text):
-        if m.group(1) not in seen:
-            seen.append(m.group(1))
-    # the pickle lists feature_names in model order; the first mention of each name is inside that list
-    return seen
 
 
 # ---------------------------------------------------------------------------------- run_vmaf
@@ -316,12 +341,76 @@ def parse_batch_file(path, prog="run_vmaf_in_batch"):
     return assets, 0
 
 
+def _device_list():
+    """GPUs to spread work over: VMAF_HIP_DEVICES="a,b,.." when set (the knob compute_vmaf and vmafossexec read too),
+    else every visible device."""
+    from . import binding
+    env = os.environ.get("VMAF_HIP_DEVICES", "").strip()
+    if env:
+        try:
+            devs = [int(t) for t in env.split(",") if t.strip() != ""]
+        except ValueError:
+            raise binding.VmafHipError(f"VMAF_HIP_DEVICES={env!r} is not a comma-separated list of device numbers")
+        if devs:
+            return devs
+    return list(range(max(1, binding.device_count())))
+
+
 def _batch_worker(device, items, model_path, phone_model, q):
-    cache = {}
-    index = {id(asset): idx for idx, asset in items}
-    for asset, luma in prefetched_assets([a for _, a in items]):
-        q.put((index[id(asset)], score_asset(asset, model_path, phone_model, device=device, engine_cache=cache, luma=luma).scores))
-    q.put(None)
+    """One worker process per GPU.  Posts (index, scores) per asset, ("error", index, message) when an asset fails, and
+    always the None sentinel last - the parent also watches the process itself, so a worker that dies without a word
+    (a signal, the OOM killer) still ends the run with an error instead of a hang."""
+    current = items[0][0] if items else -1
+    try:
+        cache = {}
+        index = {id(asset): idx for idx, asset in items}
+        for asset, luma in prefetched_assets([a for _, a in items]):
+            current = index[id(asset)]
+            q.put((current, score_asset(asset, model_path, phone_model, device=device, engine_cache=cache, luma=luma).scores))
+    except BaseException as ex:                                   # noqa: BLE001 - reported to the parent, which exits non-zero
+        q.put(("error", current, f"{type(ex).__name__}: {ex}"))
+    finally:
+        q.put(None)
+
+
+def _collect_from_workers(procs, q, assets, results, poll_s=0.5):
+    """Drain the workers' queue until every worker has posted its sentinel.  -> None, or the message of the first failure
+    (an error item, or a worker process that ended without its sentinel).  Never waits on a dead worker."""
+    import queue as queue_mod
+    done, failure = 0, None
+    while done < len(procs) and failure is None:
+        try:
+            item = q.get(timeout=poll_s)
+        except queue_mod.Empty:
+            # the queue is empty: a worker that is no longer alive will never post again
+            dead = [p for p in procs if not p.is_alive()]
+            if len(dead) > done:
+                try:
+                    item = q.get(timeout=poll_s)                  # items still in the pipe of a worker that just finished
+                except queue_mod.Empty:
+                    p = dead[0]
+                    failure = f"worker process {p.pid} ended with exit code {p.exitcode} before finishing its assets"
+                    break
+            else:
+                continue
+        if item is None:
+            done += 1
+        elif item[0] == "error":
+            a = assets[item[1]] if 0 <= item[1] < len(assets) else None
+            failure = f"asset {item[1]} ({a.ref_path} vs {a.dis_path}): {item[2]}" if a else item[2]
+        else:
+            results[item[0]] = Result(assets[item[0]], item[1])
+    if failure is not None:
+        for p in procs:                                           # exact processes this function's caller started
+            if p.is_alive():
+                p.terminate()
+    for p in procs:
+        p.join(timeout=30)
+    if failure is None:
+        bad = [p for p in procs if p.exitcode not in (0, None)]
+        if bad:
+            failure = f"worker process {bad[0].pid} ended with exit code {bad[0].exitcode}"
+    return failure
 
 
 def run_vmaf_in_batch_main(argv):
@@ -346,7 +435,10 @@ def run_vmaf_in_batch_main(argv):
 
     results = [None] * len(assets)
     from . import binding, sharding
-    ndev = binding.device_count() if parallelize else 1
+    # --parallelize: one worker process per GPU, or per entry of VMAF_HIP_DEVICES ("0,1,2,3"; an id may repeat, which puts
+    # several workers on one GPU - that is how the worker path is exercised on a one-GPU box)
+    devices = _device_list() if parallelize else [0]
+    ndev = len(devices)
     if parallelize and ndev > 1 and len(assets) > 1:
         # whole pairs per GPU, longest first, one worker process per GPU; results back in input order
         # (the reference forks one process per asset, executor.py:100-123 - here one per device)
@@ -355,19 +447,16 @@ def run_vmaf_in_batch_main(argv):
         parts = sharding.assign_pairs(costs, ndev)
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=_batch_worker, args=(d, [(i, assets[i]) for i in parts[d]], model_path, phone_model, q))
+        procs = [ctx.Process(target=_batch_worker, args=(devices[d], [(i, assets[i]) for i in parts[d]], model_path, phone_model, q))
                  for d in range(ndev) if parts[d]]
         for p in procs:
             p.start()
-        done = 0
-        while done < len(procs):
-            item = q.get()
-            if item is None:
-                done += 1
-            else:
-                results[item[0]] = Result(assets[item[0]], item[1])
-        for p in procs:
-            p.join()
+        failure = _collect_from_workers(procs, q, assets, results)
+        if failure is None and any(r is None for r in results):
+            failure = "no result for asset %d" % [r is None for r in results].index(True)
+        if failure is not None:
+            print("run_vmaf_in_batch: " + failure, file=sys.stderr)
+            return 1
     else:
         cache = {}
         for i, (a, luma) in enumerate(prefetched_assets(assets)):

@@ -434,30 +434,53 @@ int compute_vmaf_noexcept(double *score, char *fmt, int width, int height, int (
     }
 }
 
+// repeated calls with one model (a rank fusing batch after batch) parse the two model files once
+static vmaf_amd::VmafModel cached_model(const char *model_path)
+{
+    static std::mutex mu;
+    static std::map<std::string, vmaf_amd::VmafModel> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(model_path);
+    if (it == cache.end()) it = cache.emplace(model_path, vmaf_amd::load_vmaf_model(model_path)).first;
+    return it->second;
+}
+
+int vmaf_amd_model_feature_names(const char *model_path, int *n_features, char *names_out, int names_len, char *errbuf, int errbuf_len)
+{
+    try {
+        if (!model_path || !n_features) throw VmafException("bad argument");
+        const vmaf_amd::VmafModel model = cached_model(model_path);
+        *n_features = (int)model.feature_names.size();
+        if (names_out) {
+            std::string all;
+            for (size_t j = 0; j < model.feature_names.size(); ++j) all += (j ? "\n" : "") + model.feature_names[j];
+            if (names_len <= 0 || all.size() + 1 > (size_t)names_len) throw VmafException("names_out too small: " + std::to_string(all.size() + 1) + " bytes needed");
+            std::memcpy(names_out, all.c_str(), all.size() + 1);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        copy_err(errbuf, errbuf_len, e.what());
+        return 1;
+    }
+}
+
 int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip, int enable_transform,
-                                int device, double *vmaf_out, double *features_out, char *errbuf, int errbuf_len)
+                                int device, double *vmaf_out, double *features_out, int features_capacity, char *errbuf, int errbuf_len)
 {
     try {
         if (!model_path || !atoms || !vmaf_out || nframes <= 0) throw VmafException("bad argument");
-        // repeated calls with one model (a rank fusing batch after batch) parse the two model files once
-        static std::mutex mu;
-        static std::map<std::string, vmaf_amd::VmafModel> cache;
-        vmaf_amd::VmafModel model;
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            auto it = cache.find(model_path);
-            if (it == cache.end()) it = cache.emplace(model_path, vmaf_amd::load_vmaf_model(model_path)).first;
-            model = it->second;
-        }
+        const vmaf_amd::VmafModel model = cached_model(model_path);
+        const size_t D = model.feature_names.size();
+        if (features_out && (features_capacity < 0 || (size_t)features_capacity < D))
+            throw VmafException("features_out holds " + std::to_string(features_capacity) + " columns, the model has " + std::to_string(D) + " features");
         std::vector<double> a(atoms, atoms + (size_t)nframes * kAtoms), vmaf;
         std::map<std::string, std::vector<double>> feats;
         fuse(model, a, (size_t)nframes, disable_clip != 0, enable_transform != 0, device, vmaf, feats);
         std::copy(vmaf.begin(), vmaf.end(), vmaf_out);
         if (features_out) {
-            const size_t D = model.feature_names.size();
             for (size_t j = 0; j < D; ++j) {
                 const std::vector<double> &v = feats[short_feature_name(model.feature_names[j])];
-                for (int i = 0; i < nframes; ++i) features_out[(size_t)i * D + j] = v[i];
+                for (int i = 0; i < nframes; ++i) features_out[(size_t)i * features_capacity + j] = v[i];
             }
         }
         return 0;

@@ -23,6 +23,9 @@ std::string unquote(const std::string &t)
     return t.substr(a, b - a);
 }
 
+// first stack slot an opcode may touch: nothing below the innermost open mark
+size_t floor_of(const std::vector<size_t> &marks) { return marks.empty() ? 0 : marks.back(); }
+
 double parse_double_c(const std::string &t)
 {
     // strtod under the "C" numeric convention regardless of the caller's locale
@@ -61,10 +64,15 @@ PValPtr load_pickle_p0(const std::string &path)
                 if (marks.empty()) throw std::runtime_error("pickle: no mark");
                 const size_t m = marks.back();
                 marks.pop_back();
+                if (m > stack.size()) throw std::runtime_error("pickle: mark above the stack");
                 auto v = std::make_shared<PVal>();
                 if (op == 'd') {
                     v->kind = PVal::DICT;
-                    for (size_t i = m; i + 1 < stack.size(); i += 2) v->dict.emplace_back(stack[i]->str, stack[i + 1]);
+                    if ((stack.size() - m) % 2) throw std::runtime_error("pickle: odd number of dict items");
+                    for (size_t i = m; i + 1 < stack.size(); i += 2) {
+                        if (stack[i]->kind != PVal::STR) throw std::runtime_error("pickle: dict key is not a string");
+                        v->dict.emplace_back(stack[i]->str, stack[i + 1]);
+                    }
                 } else {
                     v->kind = PVal::LIST;
                     v->list.assign(stack.begin() + m, stack.end());
@@ -73,7 +81,7 @@ PValPtr load_pickle_p0(const std::string &path)
                 stack.push_back(v);
                 break;
             }
-            case 'p': if (stack.empty()) throw std::runtime_error("pickle: put on empty stack");
+            case 'p': if (stack.empty() || stack.size() - 1 < floor_of(marks)) throw std::runtime_error("pickle: put on empty stack");
                       memo[std::atoi(rest.c_str())] = stack.back(); pos = line.size(); break;
             case 'g': { auto it = memo.find(std::atoi(rest.c_str()));
                         if (it == memo.end()) throw std::runtime_error("pickle: bad memo key");
@@ -86,24 +94,26 @@ PValPtr load_pickle_p0(const std::string &path)
                         stack.push_back(v); pos = line.size(); break; }
             case 'N': stack.push_back(std::make_shared<PVal>()); break;
             case 's': {
-                if (stack.size() < 3) throw std::runtime_error("pickle: setitem underflow");
+                // the dict, the key and the value all lie above the innermost open mark
+                if (stack.size() < 3 || stack.size() - 3 < floor_of(marks)) throw std::runtime_error("pickle: setitem underflow");
                 PValPtr val = stack.back(); stack.pop_back();
                 PValPtr key = stack.back(); stack.pop_back();
                 PVal &d = *stack.back();
                 if (d.kind != PVal::DICT) throw std::runtime_error("pickle: setitem on non-dict");
+                if (key->kind != PVal::STR) throw std::runtime_error("pickle: dict key is not a string");
                 bool found = false;
                 for (auto &kv : d.dict) if (kv.first == key->str) { kv.second = val; found = true; }
                 if (!found) d.dict.emplace_back(key->str, val);
                 break;
             }
             case 'a': {
-                if (stack.size() < 2) throw std::runtime_error("pickle: append underflow");
+                if (stack.size() < 2 || stack.size() - 2 < floor_of(marks)) throw std::runtime_error("pickle: append underflow");
                 PValPtr val = stack.back(); stack.pop_back();
                 if (stack.back()->kind != PVal::LIST) throw std::runtime_error("pickle: append on non-list");
                 stack.back()->list.push_back(val);
                 break;
             }
-            case '.': if (stack.empty()) throw std::runtime_error("pickle: empty at stop");
+            case '.': if (stack.empty() || !marks.empty()) throw std::runtime_error("pickle: empty or open mark at stop");
                       return stack.back();
             case '\r': case ' ': break;
             default: throw std::runtime_error(std::string("pickle: unsupported opcode '") + op + "'");
@@ -164,7 +174,9 @@ void load_svm_text(const std::string &path, VmafModel &m)
     if (!nu_svr || !rbf || total_sv <= 0 || (int)rows.size() < total_sv) throw std::runtime_error("Error loading SVM model");
     rows.resize(total_sv);
     int dim = 0;
-    for (auto &r : rows) for (auto &it : r.items) { if (it.first < 1) throw std::runtime_error("Error loading SVM model"); dim = std::max(dim, it.first); }
+    constexpr int kMaxIndex = 4096;                       // a garbled index must not size the dense table
+    for (auto &r : rows) for (auto &it : r.items) { if (it.first < 1 || it.first > kMaxIndex) throw std::runtime_error("Error loading SVM model"); dim = std::max(dim, it.first); }
+    if (dim == 0) throw std::runtime_error("Error loading SVM model");
     m.n_sv = total_sv;
     m.dim = dim;
     m.sv.assign((size_t)total_sv * dim, 0.0);             // omitted sparse entries are zero (svm.cpp:182-216)
@@ -215,19 +227,27 @@ VmafModel load_vmaf_model(const std::string &pkl_path)
     if (!(score_clip->kind == PVal::NONE || score_clip->kind == PVal::LIST)) throw std::runtime_error("Incompatible score_clip");
     if (!(score_transform->kind == PVal::NONE || score_transform->kind == PVal::DICT)) throw std::runtime_error("Incompatible score_transform");
 
-    for (auto &v : feature_names->list) m.feature_names.push_back(v->str);
+    auto num_of = [](const PValPtr &v, const char *what) {
+        if (v->kind != PVal::NUM) throw std::runtime_error(std::string("Incompatible ") + what);
+        return v->num;
+    };
+    for (auto &v : feature_names->list) {
+        if (v->kind != PVal::STR) throw std::runtime_error("Incompatible feature_names");
+        m.feature_names.push_back(v->str);
+    }
+    if (m.feature_names.empty()) throw std::runtime_error("Incompatible feature_names");
     m.linear_rescale = is_lin;
     if (is_lin) {
-        for (auto &v : slopes->list) m.slopes.push_back(v->num);
-        for (auto &v : intercepts->list) m.intercepts.push_back(v->num);
+        for (auto &v : slopes->list) m.slopes.push_back(num_of(v, "slopes or intercepts"));
+        for (auto &v : intercepts->list) m.intercepts.push_back(num_of(v, "slopes or intercepts"));
         if (m.slopes.size() < m.feature_names.size() + 1 || m.intercepts.size() < m.feature_names.size() + 1)
             throw std::runtime_error("Incompatible slopes or intercepts");
     }
     if (score_clip->kind == PVal::LIST) {
         if (score_clip->list.size() < 2) throw std::runtime_error("Incompatible score_clip");
         m.has_clip = true;
-        m.clip_lo = score_clip->list[0]->num;
-        m.clip_hi = score_clip->list[1]->num;
+        m.clip_lo = num_of(score_clip->list[0], "score_clip");
+        m.clip_hi = num_of(score_clip->list[1], "score_clip");
     }
     if (score_transform->kind == PVal::DICT) {
         ScoreTransform &t = m.transform;

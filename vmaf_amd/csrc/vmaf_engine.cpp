@@ -21,6 +21,7 @@
 #include <new>
 
 #include "../../include/vmaf_hip.h"
+#include "../../include/vmaf_hip_debug.h"
 #include "vmaf_kernels.h"
 
 namespace {
@@ -61,8 +62,28 @@ float adm_rfactor(int lambda, int theta)
 
 constexpr int kDepth = 2;
 
-struct vmaf_hip_engine {
-    int device = 0, w = 0, h = 0, max_batch = 0;
+// Everything that follows from the frame size and the batch size alone: plane sizes per scale, tiles per kernel, where each
+// kernel's per-workgroup partial sums start in the partial buffer, ADM constants.  Shared by the engine and by the
+// allocation-free entry point, which lays the same buffers out in the static scratch area.
+struct Geometry {
+    int w = 0, h = 0, max_batch = 0;
+    int vw[4], vh[4];              // VIF plane size per scale
+    int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
+    size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
+    int tiles_vif[4], tiles_adm[4], tiles_mot;
+    float rfac[8];
+    int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
+};
+
+// Device buffers of one batch in flight (engine: hipMalloc'd at create; no-alloc entry: carved from the static scratch)
+struct FeatureBuffers {
+    float *vif_ref[4] = {}, *vif_dis[4] = {};   // [1..3]
+    float *adm_ref[4] = {}, *adm_dis[4] = {};   // [1..3] = LL of level 0..2
+    double *partials = nullptr, *sums_dev = nullptr;
+};
+
+struct vmaf_hip_engine : Geometry, FeatureBuffers {
+    int device = 0;
     hipStream_t s_main = nullptr, s_adm = nullptr, s_mot = nullptr;
     hipEvent_t ev_in = nullptr, ev_adm = nullptr, ev_mot = nullptr;
     hipEvent_t ev_t0[kDepth] = {}, ev_t1[kDepth] = {}, ev_k0[kDepth] = {}, ev_k1[kDepth] = {}, ev_done[kDepth] = {};
@@ -70,20 +91,16 @@ struct vmaf_hip_engine {
     bool serial = false;
     int order = 1;                 // convolution tap order: 1 = reference AVX path (default), 0 = scalar path, 2 = fused (fast, not bit-exact)
 
-    int vw[4], vh[4];              // VIF plane size per scale
-    int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
-    float *vif_ref[4] = {}, *vif_dis[4] = {};   // [1..3]
-    float *adm_ref[4] = {}, *adm_dis[4] = {};   // [1..3] = LL of level 0..2
-    unsigned char *raw_ref = nullptr, *raw_dis = nullptr;   // device copies of raw 8/16-bit luma (allocated on first use)
+    // host-pointer entry points: the H2D copies of call k+1 run on s_copy while the kernels of call k run, into the
+    // staging set of their own pending slot (raw 8/16-bit luma, or fp32 planes for the reference's read_frame contract)
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_copy[kDepth] = {};
+    unsigned char *raw_ref[kDepth] = {}, *raw_dis[kDepth] = {};   // allocated on first use
     float *carry[2] = {};
     int carry_cur = 0;
     bool carry_valid = false;
-    float *stage_ref = nullptr, *stage_dis = nullptr;
-    double *partials = nullptr, *sums_dev = nullptr, *sums_host[kDepth] = {};
-    size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
-    int tiles_vif[4], tiles_adm[4], tiles_mot;
-    float rfac[8];
-    int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
+    float *stage_ref[kDepth] = {}, *stage_dis[kDepth] = {};      // fp32 planes; [1] allocated on first use by the fp32 host path
+    double *sums_host[kDepth] = {};
 
     // optional metrics (combo.c:168-230): PSNR, SSIM, MS-SSIM on the un-offset planes
     bool m_psnr = false, m_ssim = false, m_ms = false, m_ansnr = false;
@@ -107,7 +124,7 @@ struct vmaf_hip_engine {
 namespace {
 
 // Finish one frame: VK_NSUMS raw fp64 sums -> 20 atoms, in the reference's own precision steps.
-void finish_atoms(const vmaf_hip_engine *e, const double *s, bool has_motion, double *atoms)
+void finish_atoms(const Geometry *e, const double *s, bool has_motion, double *atoms)
 {
     // vif.c:265-291: vif_sum returns float; per-scale values widen to double, totals add in double
     double vnum = 0, vden = 0;
@@ -172,7 +189,69 @@ void finish_metrics(const vmaf_hip_engine *e, const double *s, double *m)
     }
 }
 
+void geometry_init(Geometry *g, int width, int height, int max_batch)
+{
+    g->w = width; g->h = height; g->max_batch = max_batch;
+    const size_t B = (size_t)max_batch;
+    g->vw[0] = width; g->vh[0] = height;
+    for (int s = 1; s < 4; ++s) { g->vw[s] = g->vw[s - 1] / 2; g->vh[s] = g->vh[s - 1] / 2; }      // vif.c:172-173
+    g->aw[0] = width; g->ah[0] = height;
+    for (int s = 1; s < 5; ++s) { g->aw[s] = (g->aw[s - 1] + 1) / 2; g->ah[s] = (g->ah[s - 1] + 1) / 2; }  // adm.c:135-136
+    for (int s = 0; s < 4; ++s) {
+        g->rfac[2 * s] = adm_rfactor(s, 1);
+        g->rfac[2 * s + 1] = adm_rfactor(s, 2);
+        const int bw = g->aw[s + 1], bh = g->ah[s + 1];
+        const int left = (int)(bw * 0.1 - 0.5), top = (int)(bh * 0.1 - 0.5);                  // adm_tools.c:54-57
+        g->win[s][0] = left; g->win[s][1] = top; g->win[s][2] = bw - left; g->win[s][3] = bh - top;
+    }
+    size_t off = 0;
+    for (int s = 0; s < 4; ++s) { g->tiles_vif[s] = vk_vif_tiles(g->vw[s], g->vh[s]); g->part_off_vif[s] = off; off += B * g->tiles_vif[s] * 2; }
+    for (int s = 0; s < 4; ++s) { g->tiles_adm[s] = vk_adm_tiles(g->aw[s], g->ah[s]); g->part_off_adm[s] = off; off += B * g->tiles_adm[s] * 6; }
+    g->tiles_mot = vk_motion_tiles(width, height); g->part_off_mot = off; off += B * g->tiles_mot;
+    g->part_total = off;
+}
+
 int alloc_planes(float **p, size_t floats) { HIP_TRY(hipMalloc((void **)p, floats * sizeof(float))); return 0; }
+
+// Where a chain reads its current scale from: the caller's planes at scale 0, the pyramid buffers afterwards.
+struct PlaneCursor { const float *ref, *dis; size_t frame_stride; int row_stride; };
+
+// One VIF scale: statistic + (sc < 3) the next scale's planes, both from one read of the current planes (vif.c:157-269)
+int launch_vif_scale(const Geometry *g, const FeatureBuffers *b, int order, int sc, PlaneCursor *c, int nframes, hipStream_t s)
+{
+    float *nr = sc < 3 ? b->vif_ref[sc + 1] : nullptr, *nd = sc < 3 ? b->vif_dis[sc + 1] : nullptr;
+    const size_t nfs = sc < 3 ? (size_t)g->vw[sc + 1] * g->vh[sc + 1] : 0;
+    const int nrs = sc < 3 ? g->vw[sc + 1] : 0;
+    HIP_TRY(vk_launch_vif_stat(sc, order, c->ref, c->dis, c->frame_stride, c->row_stride, g->vw[sc], g->vh[sc], nframes,
+                               b->partials + g->part_off_vif[sc], nr, nd, nfs, nrs, s));
+    *c = { nr, nd, nfs, nrs };
+    return 0;
+}
+
+// One ADM scale (adm.c:132-247); its LL bands are the next scale's input
+int launch_adm_scale(const Geometry *g, const FeatureBuffers *b, int order, int sc, PlaneCursor *c, int nframes, hipStream_t s)
+{
+    const int bw = g->aw[sc + 1], bh = g->ah[sc + 1];
+    const size_t lfs = (size_t)bw * bh;
+    float *lr = sc < 3 ? b->adm_ref[sc + 1] : nullptr, *ld = sc < 3 ? b->adm_dis[sc + 1] : nullptr;
+    HIP_TRY(vk_launch_adm_scale(sc, order, c->ref, c->dis, c->frame_stride, c->row_stride, g->aw[sc], g->ah[sc], lr, ld, lfs, bw,
+                                g->rfac[2 * sc], g->rfac[2 * sc + 1], g->win[sc][0], g->win[sc][1], g->win[sc][2], g->win[sc][3], nframes,
+                                b->partials + g->part_off_adm[sc], s));
+    *c = { lr, ld, lfs, bw };
+    return 0;
+}
+
+// Sections [0..32] of the reduction table: VIF num/den x 4 scales, ADM 6 x 4 scales, motion.  Returns the next index.
+int fill_reduce_table(const Geometry *g, vk_reduce_table *tab)
+{
+    int q = 0;
+    for (int sc = 0; sc < 4; ++sc)
+        for (int c = 0; c < 2; ++c) tab->d[q++] = { g->part_off_vif[sc], g->tiles_vif[sc], 2, c };
+    for (int sc = 0; sc < 4; ++sc)
+        for (int c = 0; c < 6; ++c) tab->d[q++] = { g->part_off_adm[sc], g->tiles_adm[sc], 6, c };
+    tab->d[q++] = { g->part_off_mot, g->tiles_mot, 1, 0 };
+    return q;
+}
 
 int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
                   size_t frame_stride_bytes, int nframes, int continue_sequence)
@@ -232,37 +311,22 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     }
 
     // ---- VIF chain (vif.c:130-275) on s_main
-    const float *cr = d_ref, *cd = d_dis;
-    size_t cfs = fs;
-    int crs = rs;
+    PlaneCursor vc = { d_ref, d_dis, fs, rs };
     for (int sc = 0; sc < 4; ++sc) {
-        // scale sc: statistic + (sc < 3) the next scale's planes, both from one read of the current planes
-        float *nr = sc < 3 ? e->vif_ref[sc + 1] : nullptr, *nd = sc < 3 ? e->vif_dis[sc + 1] : nullptr;
-        const size_t nfs = sc < 3 ? (size_t)e->vw[sc + 1] * e->vh[sc + 1] : 0;
-        const int nrs = sc < 3 ? e->vw[sc + 1] : 0;
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0[slot], e->s_main));
-        HIP_TRY(vk_launch_vif_stat(sc, e->order, cr, cd, cfs, crs, e->vw[sc], e->vh[sc], nframes, e->partials + e->part_off_vif[sc],
-                                   nr, nd, nfs, nrs, e->s_main));
+        if (launch_vif_scale(e, e, e->order, sc, &vc, nframes, e->s_main)) return 1;
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k1[slot], e->s_main));
         if (sc == 0 && !adm_early) {
             HIP_TRY(hipEventRecord(e->ev_in, e->s_main));
             HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
             HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
         }
-        cr = nr; cd = nd; cfs = nfs; crs = nrs;
     }
 
     // ---- ADM chain (adm.c:125-254) on s_adm
-    cr = d_ref; cd = d_dis; cfs = fs; crs = rs;
-    for (int sc = 0; sc < 4; ++sc) {
-        const int bw = e->aw[sc + 1], bh = e->ah[sc + 1];
-        const size_t lfs = (size_t)bw * bh;
-        float *lr = sc < 3 ? e->adm_ref[sc + 1] : nullptr, *ld = sc < 3 ? e->adm_dis[sc + 1] : nullptr;
-        HIP_TRY(vk_launch_adm_scale(sc, e->order, cr, cd, cfs, crs, e->aw[sc], e->ah[sc], lr, ld, lfs, bw, e->rfac[2 * sc], e->rfac[2 * sc + 1],
-                                    e->win[sc][0], e->win[sc][1], e->win[sc][2], e->win[sc][3], nframes,
-                                    e->partials + e->part_off_adm[sc], e->s_adm));
-        cr = lr; cd = ld; cfs = lfs; crs = bw;
-    }
+    PlaneCursor ac = { d_ref, d_dis, fs, rs };
+    for (int sc = 0; sc < 4; ++sc)
+        if (launch_adm_scale(e, e, e->order, sc, &ac, nframes, e->s_adm)) return 1;
     HIP_TRY(hipEventRecord(e->ev_adm, e->s_adm));
 
     // ---- motion (combo.c:309-326) on s_mot
@@ -277,13 +341,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_mot, 0));
     if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_iqa, 0));
     vk_reduce_table tab;
-    int q = 0;
-    for (int sc = 0; sc < 4; ++sc)
-        for (int c = 0; c < 2; ++c)
-            tab.d[q++] = { e->part_off_vif[sc], e->tiles_vif[sc], 2, c };
-    for (int sc = 0; sc < 4; ++sc)
-        for (int c = 0; c < 6; ++c) tab.d[q++] = { e->part_off_adm[sc], e->tiles_adm[sc], 6, c };
-    tab.d[q++] = { e->part_off_mot, e->tiles_mot, 1, 0 };
+    int q = fill_reduce_table(e, &tab);
     tab.d[q++] = { e->part_off_psnr, e->m_psnr ? e->tiles_psnr : 0, 1, 0 };
     for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c };
     for (int i = 0; i < 5; ++i)
@@ -363,20 +421,10 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
 
     vmaf_hip_engine *e = new (std::nothrow) vmaf_hip_engine();
     if (!e) return fail("out of host memory");
-    e->device = device; e->w = width; e->h = height; e->max_batch = max_batch;
+    e->device = device;
     const size_t B = (size_t)max_batch;
 
-    e->vw[0] = width; e->vh[0] = height;
-    for (int s = 1; s < 4; ++s) { e->vw[s] = e->vw[s - 1] / 2; e->vh[s] = e->vh[s - 1] / 2; }      // vif.c:172-173
-    e->aw[0] = width; e->ah[0] = height;
-    for (int s = 1; s < 5; ++s) { e->aw[s] = (e->aw[s - 1] + 1) / 2; e->ah[s] = (e->ah[s - 1] + 1) / 2; }  // adm.c:135-136
-    for (int s = 0; s < 4; ++s) {
-        e->rfac[2 * s] = adm_rfactor(s, 1);
-        e->rfac[2 * s + 1] = adm_rfactor(s, 2);
-        const int bw = e->aw[s + 1], bh = e->ah[s + 1];
-        const int left = (int)(bw * 0.1 - 0.5), top = (int)(bh * 0.1 - 0.5);                  // adm_tools.c:54-57
-        e->win[s][0] = left; e->win[s][1] = top; e->win[s][2] = bw - left; e->win[s][3] = bh - top;
-    }
+    geometry_init(e, width, height, max_batch);
 
     int rc = 0;
     auto cleanup = [&]() { vmaf_hip_engine_destroy(e); return 1; };
@@ -384,10 +432,11 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     const char *ser = getenv("VMAF_HIP_SERIAL");
     e->serial = ser && *ser && *ser != '0';
     if (hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
-    if (e->serial) { e->s_adm = e->s_main; e->s_mot = e->s_main; }
+    if (e->serial) { e->s_adm = e->s_main; e->s_mot = e->s_main; e->s_copy = e->s_main; }
     else if (hipStreamCreateWithFlags(&e->s_adm, hipStreamNonBlocking) != hipSuccess ||
-             hipStreamCreateWithFlags(&e->s_mot, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
-    hipEvent_t *evs[] = { &e->ev_in, &e->ev_adm, &e->ev_mot };
+             hipStreamCreateWithFlags(&e->s_mot, hipStreamNonBlocking) != hipSuccess ||
+             hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
+    hipEvent_t *evs[] = { &e->ev_in, &e->ev_adm, &e->ev_mot, &e->ev_copy[0], &e->ev_copy[1] };
     for (auto ev : evs)
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
     for (int i = 0; i < kDepth; ++i) {
@@ -403,18 +452,10 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
         rc |= alloc_planes(&e->adm_dis[s], B * e->aw[s] * e->ah[s]);
     }
     for (int i = 0; i < 2 && !rc; ++i) rc |= alloc_planes(&e->carry[i], (size_t)width * height);
-    if (!rc) rc |= alloc_planes(&e->stage_ref, B * width * height);
-    if (!rc) rc |= alloc_planes(&e->stage_dis, B * width * height);
+    if (!rc) rc |= alloc_planes(&e->stage_ref[0], B * width * height);
+    if (!rc) rc |= alloc_planes(&e->stage_dis[0], B * width * height);
 
-    size_t off = 0;
-    for (int s = 0; s < 4; ++s) {
-        e->tiles_vif[s] = vk_vif_tiles(e->vw[s], e->vh[s]);
-        e->part_off_vif[s] = off;
-        off += B * e->tiles_vif[s] * 2;
-    }
-    for (int s = 0; s < 4; ++s) { e->tiles_adm[s] = vk_adm_tiles(e->aw[s], e->ah[s]); e->part_off_adm[s] = off; off += B * e->tiles_adm[s] * 6; }
-    e->tiles_mot = vk_motion_tiles(width, height); e->part_off_mot = off; off += B * e->tiles_mot;
-    e->part_total = off;
+    const size_t off = e->part_total;
     if (!rc && hipMalloc((void **)&e->partials, off * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(partials) failed");
     if (!rc && hipMalloc((void **)&e->sums_dev, B * VK_NSUMS * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(sums) failed");
     for (int i = 0; i < kDepth && !rc; ++i)
@@ -434,21 +475,27 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
         (void)hipFree(e->adm_ref[s]); (void)hipFree(e->adm_dis[s]);
     }
     (void)hipFree(e->carry[0]); (void)hipFree(e->carry[1]);
-    (void)hipFree(e->stage_ref); (void)hipFree(e->stage_dis);
-    (void)hipFree(e->raw_ref); (void)hipFree(e->raw_dis);
+    for (int i = 0; i < kDepth; ++i) {
+        (void)hipFree(e->stage_ref[i]); (void)hipFree(e->stage_dis[i]);
+        (void)hipFree(e->raw_ref[i]); (void)hipFree(e->raw_dis[i]);
+    }
     (void)hipFree(e->ssim_ref); (void)hipFree(e->ssim_dis);
     for (int i = 1; i < 5; ++i) { (void)hipFree(e->ms_ref[i]); (void)hipFree(e->ms_dis[i]); }
     if (e->ev_iqa) (void)hipEventDestroy(e->ev_iqa);
     if (e->s_iqa && e->s_iqa != e->s_main) (void)hipStreamDestroy(e->s_iqa);
     (void)hipFree(e->partials); (void)hipFree(e->sums_dev);
-    hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot };
+    hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_copy[0], e->ev_copy[1] };
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < kDepth; ++i) {
         if (e->sums_host[i]) (void)hipHostFree(e->sums_host[i]);
         hipEvent_t tevs[] = { e->ev_t0[i], e->ev_t1[i], e->ev_k0[i], e->ev_k1[i], e->ev_done[i] };
         for (auto ev : tevs) if (ev) (void)hipEventDestroy(ev);
     }
-    if (!e->serial) { if (e->s_adm) (void)hipStreamDestroy(e->s_adm); if (e->s_mot) (void)hipStreamDestroy(e->s_mot); }
+    if (!e->serial) {
+        if (e->s_adm) (void)hipStreamDestroy(e->s_adm);
+        if (e->s_mot) (void)hipStreamDestroy(e->s_mot);
+        if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
+    }
     if (e->s_main) (void)hipStreamDestroy(e->s_main);
     delete e;
 }
@@ -594,21 +641,44 @@ int vmaf_hip_extract_device(vmaf_hip_engine *e, const float *d_ref, const float 
     return vmaf_hip_engine_sync(e);
 }
 
+// The slot the next asynchronous call takes.  Its staging buffers are free: the call that used them last (two calls ago)
+// has been synchronised by the caller, or check_call would have refused this one.
+static int ensure_stage(vmaf_hip_engine *e, int slot);
+static int next_slot(const vmaf_hip_engine *e) { return (e->pend_head + e->pend_count) % kDepth; }
+
+// Called after the H2D copies of a host-pointer call were put on s_copy: the kernels on s_main wait for them, and only
+// for them - the copies of the next call overlap these kernels.
+static int copies_done(vmaf_hip_engine *e, int slot)
+{
+    if (e->s_copy == e->s_main) return 0;
+    HIP_TRY(hipEventRecord(e->ev_copy[slot], e->s_copy));
+    HIP_TRY(hipStreamWaitEvent(e->s_main, e->ev_copy[slot], 0));
+    return 0;
+}
+
 int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const float *h_dis, size_t row_stride_bytes,
                           size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
 {
     if (check_call(e, h_ref, h_dis, nframes, atoms_out)) return 1;
     if (row_stride_bytes < (size_t)e->w * 4) return fail("row stride %zu smaller than a row", row_stride_bytes);
+    const int slot = next_slot(e);
+    if (ensure_stage(e, slot)) return 1;
     // stage densely (row stride = w floats) so the kernels see one geometry
     const size_t dense_row = (size_t)e->w * 4, dense_frame = dense_row * e->h;
-    for (int f = 0; f < nframes; ++f) {
-        const char *sr = (const char *)h_ref + (size_t)f * frame_stride_bytes, *sd = (const char *)h_dis + (size_t)f * frame_stride_bytes;
-        HIP_TRY(hipMemcpy2DAsync((char *)e->stage_ref + f * dense_frame, dense_row, sr, row_stride_bytes, dense_row, e->h,
-                                 hipMemcpyHostToDevice, e->s_main));
-        HIP_TRY(hipMemcpy2DAsync((char *)e->stage_dis + f * dense_frame, dense_row, sd, row_stride_bytes, dense_row, e->h,
-                                 hipMemcpyHostToDevice, e->s_main));
+    if (row_stride_bytes == dense_row && (nframes == 1 || frame_stride_bytes == dense_frame)) {
+        HIP_TRY(hipMemcpyAsync(e->stage_ref[slot], h_ref, dense_frame * nframes, hipMemcpyHostToDevice, e->s_copy));
+        HIP_TRY(hipMemcpyAsync(e->stage_dis[slot], h_dis, dense_frame * nframes, hipMemcpyHostToDevice, e->s_copy));
+    } else {
+        for (int f = 0; f < nframes; ++f) {
+            const char *sr = (const char *)h_ref + (size_t)f * frame_stride_bytes, *sd = (const char *)h_dis + (size_t)f * frame_stride_bytes;
+            HIP_TRY(hipMemcpy2DAsync((char *)e->stage_ref[slot] + f * dense_frame, dense_row, sr, row_stride_bytes, dense_row, e->h,
+                                     hipMemcpyHostToDevice, e->s_copy));
+            HIP_TRY(hipMemcpy2DAsync((char *)e->stage_dis[slot] + f * dense_frame, dense_row, sd, row_stride_bytes, dense_row, e->h,
+                                     hipMemcpyHostToDevice, e->s_copy));
+        }
     }
-    if (enqueue_batch(e, e->stage_ref, e->stage_dis, dense_row, dense_frame, nframes, continue_sequence)) return 1;
+    if (copies_done(e, slot)) return 1;
+    if (enqueue_batch(e, e->stage_ref[slot], e->stage_dis[slot], dense_row, dense_frame, nframes, continue_sequence)) return 1;
     push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
@@ -632,13 +702,25 @@ static int check_raw(vmaf_hip_engine *e, int bytes_per_sample, size_t row_stride
     return 0;
 }
 
+// second fp32 staging set, for the call in pending slot 1: only callers that keep two host-pointer or raw calls in flight pay for it
+static int ensure_stage(vmaf_hip_engine *e, int slot)
+{
+    if (e->stage_ref[slot]) return 0;
+    const size_t floats = (size_t)e->max_batch * e->w * e->h;
+    return alloc_planes(&e->stage_ref[slot], floats) || alloc_planes(&e->stage_dis[slot], floats);
+}
+
 static int widen_and_enqueue(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bps, size_t rs, size_t fs, int nframes,
                              int continue_sequence, double *atoms_out)
 {
-    HIP_TRY(vk_launch_widen(d_ref, bps, rs, fs, e->stage_ref, e->w, e->h, nframes, e->s_main));
-    HIP_TRY(vk_launch_widen(d_dis, bps, rs, fs, e->stage_dis, e->w, e->h, nframes, e->s_main));
+    // every call in flight owns the staging set of its pending slot: one rule for the raw and the fp32 host paths, so that
+    // mixing them on one engine stays safe (an fp32 host call copies into its set on s_copy while the previous call runs)
+    const int slot = next_slot(e);
+    if (ensure_stage(e, slot)) return 1;
+    HIP_TRY(vk_launch_widen(d_ref, bps, rs, fs, e->stage_ref[slot], e->w, e->h, nframes, e->s_main));
+    HIP_TRY(vk_launch_widen(d_dis, bps, rs, fs, e->stage_dis[slot], e->w, e->h, nframes, e->s_main));
     const size_t dense_row = (size_t)e->w * 4, dense_frame = dense_row * e->h;
-    if (enqueue_batch(e, e->stage_ref, e->stage_dis, dense_row, dense_frame, nframes, continue_sequence)) return 1;
+    if (enqueue_batch(e, e->stage_ref[slot], e->stage_dis[slot], dense_row, dense_frame, nframes, continue_sequence)) return 1;
     push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
@@ -659,22 +741,24 @@ int vmaf_hip_extract_host_raw_async(vmaf_hip_engine *e, const void *h_ref, const
     if (check_call(e, h_ref, h_dis, nframes, atoms_out)) return 1;
     if (check_raw(e, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes)) return 1;
     const size_t dense_row = (size_t)e->w * bytes_per_sample, dense_frame = dense_row * e->h;
-    if (!e->raw_ref) {
+    const int slot = next_slot(e);
+    if (!e->raw_ref[slot]) {
         const size_t bytes = (size_t)e->max_batch * e->w * e->h * 2;
-        if (hipMalloc((void **)&e->raw_ref, bytes) != hipSuccess || hipMalloc((void **)&e->raw_dis, bytes) != hipSuccess)
+        if (hipMalloc((void **)&e->raw_ref[slot], bytes) != hipSuccess || hipMalloc((void **)&e->raw_dis[slot], bytes) != hipSuccess)
             return fail("hipMalloc(raw luma staging, 2 x %zu bytes) failed", bytes);
     }
     if (row_stride_bytes == dense_row && (nframes == 1 || frame_stride_bytes == dense_frame)) {
-        HIP_TRY(hipMemcpyAsync(e->raw_ref, h_ref, dense_frame * nframes, hipMemcpyHostToDevice, e->s_main));
-        HIP_TRY(hipMemcpyAsync(e->raw_dis, h_dis, dense_frame * nframes, hipMemcpyHostToDevice, e->s_main));
+        HIP_TRY(hipMemcpyAsync(e->raw_ref[slot], h_ref, dense_frame * nframes, hipMemcpyHostToDevice, e->s_copy));
+        HIP_TRY(hipMemcpyAsync(e->raw_dis[slot], h_dis, dense_frame * nframes, hipMemcpyHostToDevice, e->s_copy));
     } else {
         for (int f = 0; f < nframes; ++f) {
             const char *sr = (const char *)h_ref + (size_t)f * frame_stride_bytes, *sd = (const char *)h_dis + (size_t)f * frame_stride_bytes;
-            HIP_TRY(hipMemcpy2DAsync(e->raw_ref + f * dense_frame, dense_row, sr, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
-            HIP_TRY(hipMemcpy2DAsync(e->raw_dis + f * dense_frame, dense_row, sd, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+            HIP_TRY(hipMemcpy2DAsync(e->raw_ref[slot] + f * dense_frame, dense_row, sr, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_copy));
+            HIP_TRY(hipMemcpy2DAsync(e->raw_dis[slot] + f * dense_frame, dense_row, sd, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_copy));
         }
     }
-    return widen_and_enqueue(e, e->raw_ref, e->raw_dis, bytes_per_sample, dense_row, dense_frame, nframes, continue_sequence, atoms_out);
+    if (copies_done(e, slot)) return 1;
+    return widen_and_enqueue(e, e->raw_ref[slot], e->raw_dis[slot], bytes_per_sample, dense_row, dense_frame, nframes, continue_sequence, atoms_out);
 }
 
 int vmaf_hip_extract_host_raw(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample, size_t row_stride_bytes,
@@ -703,10 +787,10 @@ int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int byt
     HIP_TRY(hipSetDevice(e->device));
     // the float staging plane doubles as the landing area of the raw rows (its tail) - one frame only
     const size_t dense_row = (size_t)e->w * bytes_per_sample;
-    unsigned char *tmp = (unsigned char *)(e->stage_dis);
+    unsigned char *tmp = (unsigned char *)(e->stage_dis[0]);
     HIP_TRY(hipMemcpy2DAsync(tmp, dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
-    HIP_TRY(vk_launch_widen(tmp, bytes_per_sample, dense_row, dense_row * e->h, e->stage_ref, e->w, e->h, 1, e->s_main));
-    return vmaf_hip_motion_seed_device(e, e->stage_ref, (size_t)e->w * 4);
+    HIP_TRY(vk_launch_widen(tmp, bytes_per_sample, dense_row, dense_row * e->h, e->stage_ref[0], e->w, e->h, 1, e->s_main));
+    return vmaf_hip_motion_seed_device(e, e->stage_ref[0], (size_t)e->w * 4);
 }
 
 void *vmaf_hip_host_alloc(size_t bytes)
@@ -739,8 +823,9 @@ int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row
     if (row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
     HIP_TRY(hipSetDevice(e->device));
     const size_t dense_row = (size_t)e->w * 4;
-    HIP_TRY(hipMemcpy2DAsync(e->stage_ref, dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
-    return vmaf_hip_motion_seed_device(e, e->stage_ref, dense_row);
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
+    HIP_TRY(hipMemcpy2DAsync(e->stage_ref[0], dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+    return vmaf_hip_motion_seed_device(e, e->stage_ref[0], dense_row);
 }
 
 int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho,
