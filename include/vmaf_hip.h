@@ -26,6 +26,8 @@
  *   - vmaf_hip_last_error() is per calling thread.  vmaf_hip_svm_predict, vmaf_hip_host_alloc/free and
  *     vmaf_hip_device_count keep no state and may be called from any thread at any time.
  *   - Every call makes the engine's device current on the calling thread (hipSetDevice) and leaves it so.
+ *   - vmaf_hip_extract_device_noalloc uses one static scratch area per GPU: calls on the same GPU must not overlap
+ *     (see its comment); it is independent of engines.
  * Debug / profiling hooks live in include/vmaf_hip_debug.h.
  */
 #ifndef VMAF_HIP_H_
@@ -168,6 +170,27 @@ int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int byt
 int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit);
 int vmaf_hip_engine_enable_ansnr(vmaf_hip_engine *e, int ten_bit);
 int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes);
+
+/*
+ * The entry point that allocates nothing.  No counterpart in the reference: it exists for callers that cannot call
+ * hipMalloc - code under HIP graph capture, tight serving loops, harnesses that forbid allocation - and so cannot
+ * create an engine.  Same result as vmaf_hip_engine_create + vmaf_hip_extract_device(continue_sequence = 0) +
+ * vmaf_hip_engine_destroy on the same frames, bit for bit (same kernels, same reduction): the 20 atoms of `nframes`
+ * consecutive frames starting a video (motion of frame 0 is 0).  d_ref / d_dis: device pointers on `device`, un-offset
+ * fp32 luma as for vmaf_hip_extract_device; conv_order as vmaf_hip_engine_set_conv_order; stream: a hipStream_t on that
+ * device (NULL = the default stream) that all launches go to; atoms_out: host, complete on return.
+ * Everything the kernels need beyond the inputs (pyramid planes, LL bands, partial and reduced sums) lives in ONE static
+ * device array of VMAF_HIP_NOALLOC_SCRATCH_BYTES per GPU, held from library load to process end.  The call makes no
+ * hipMalloc / hipFree / hipHostMalloc and creates no stream or event.  A request that does not fit is refused with a
+ * message (vmaf_hip_noalloc_scratch_needed tells in advance; 0 = invalid arguments): 32 MiB hold e.g. two 1920x1080
+ * frames, 6 of 1280x720 or 33 of 576x324 per call; one 3840x2160 frame (74 MB) does not fit.  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on the same GPU (other threads, other streams) race and must be serialised by the caller.
+ */
+#define VMAF_HIP_NOALLOC_SCRATCH_BYTES (32u << 20)
+size_t vmaf_hip_noalloc_scratch_needed(int width, int height, int nframes);
+int vmaf_hip_extract_device_noalloc(int device, void *stream, const float *d_ref, const float *d_dis, int width, int height,
+                                    size_t row_stride_bytes, size_t frame_stride_bytes, int nframes, int conv_order,
+                                    double *atoms_out);
 
 /*
  * Batched nu-SVR RBF prediction.  Replaces the per-frame svm_predict() call site

@@ -70,6 +70,9 @@ def load_library():
     L.vmaf_hip_host_free.restype = None
     L.vmaf_hip_motion_seed_device.argtypes = [vp, vp, sz]
     L.vmaf_hip_motion_seed_host.argtypes = [vp, vp, sz]
+    L.vmaf_hip_noalloc_scratch_needed.argtypes = [i, i, i]
+    L.vmaf_hip_noalloc_scratch_needed.restype = sz
+    L.vmaf_hip_extract_device_noalloc.argtypes = [i, vp, vp, vp, i, i, sz, sz, i, i, _dp]
     L.vmaf_hip_svm_predict.argtypes = [i, _dp, _dp, i, i, C.c_double, C.c_double, _dp, i, _dp]
     L.vmaf_hip_last_kernel_ms.argtypes = [vp, i]
     L.vmaf_hip_last_kernel_ms.restype = C.c_double
@@ -273,6 +276,25 @@ class Engine:
 
     def last_kernel_ms(self, which=0):
         return self.L.vmaf_hip_last_kernel_ms(self._h, which)
+
+
+NOALLOC_SCRATCH_BYTES = 32 << 20
+
+
+def extract_device_noalloc(d_ref, d_dis, width, height, nframes, device=0, order="avx", stream=None,
+                           row_stride_bytes=None, frame_stride_bytes=None):
+    """vmaf_hip_extract_device_noalloc: atoms [nframes,20] of device-resident fp32 planes without any allocation on the
+    library's side (static per-GPU scratch area; see include/vmaf_hip.h for its limit and the no-overlap rule)."""
+    L = load_library()
+    pr = d_ref.data_ptr() if hasattr(d_ref, "data_ptr") else int(d_ref)
+    pd = d_dis.data_ptr() if hasattr(d_dis, "data_ptr") else int(d_dis)
+    rs = row_stride_bytes or width * 4
+    fs = frame_stride_bytes or rs * height
+    out = np.zeros((nframes, N_ATOMS))
+    if L.vmaf_hip_extract_device_noalloc(device, stream, pr, pd, width, height, rs, fs, nframes,
+                                         {"avx": 1, "scalar": 0, "fma": 2}[order], out.ctypes.data_as(_dp)):
+        raise VmafHipError(_err(L))
+    return out
 
 
 class PinnedArray:

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/vmaf_hip.h"
@@ -393,6 +394,61 @@ int finish_oldest(vmaf_hip_engine *e)
     return 0;
 }
 
+}  // namespace
+
+// ---- the entry point that allocates nothing (include/vmaf_hip.h: vmaf_hip_extract_device_noalloc) ----
+// Its device memory beyond the caller's inputs - the VIF pyramid, the ADM LL bands, the blurred plane the motion kernel
+// leaves behind, every kernel's per-workgroup partial sums and the reduced sums - lives in this file-scope array.
+// In host code the NAME `scratch` is only the host-side stand-in of the symbol, never a device address: each GPU holds its
+// own copy at its own address, looked up once per device with hipGetSymbolAddress and kept in g_noalloc_ptr[device].
+static __device__ __align__(256) unsigned char scratch[VMAF_HIP_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_noalloc_mu;
+unsigned char *g_noalloc_ptr[kMaxDevices] = {};
+
+// device address of this GPU's copy of `scratch` (device must be current)
+int noalloc_scratch(int device, unsigned char **out)
+{
+    std::lock_guard<std::mutex> lock(g_noalloc_mu);
+    if (!g_noalloc_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail("hipGetSymbolAddress returned a null address for the static scratch area");
+        g_noalloc_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_noalloc_ptr[device];
+    return 0;
+}
+
+// carve n bytes, 256-byte aligned, from the scratch area; only sizes the layout when base is null
+template <typename T> T *carve(unsigned char *base, size_t *off, size_t n)
+{
+    const size_t at = (*off + 255) & ~(size_t)255;
+    *off = at + n * sizeof(T);
+    return base ? reinterpret_cast<T *>(base + at) : nullptr;
+}
+
+struct NoallocLayout { FeatureBuffers b; float *carry = nullptr; size_t bytes = 0; };
+
+NoallocLayout noalloc_layout(const Geometry &g, int nframes, unsigned char *base)
+{
+    NoallocLayout L;
+    size_t off = 0;
+    const size_t B = (size_t)nframes;
+    for (int s = 1; s < 4; ++s) {
+        L.b.vif_ref[s] = carve<float>(base, &off, B * g.vw[s] * g.vh[s]);
+        L.b.vif_dis[s] = carve<float>(base, &off, B * g.vw[s] * g.vh[s]);
+        L.b.adm_ref[s] = carve<float>(base, &off, B * g.aw[s] * g.ah[s]);
+        L.b.adm_dis[s] = carve<float>(base, &off, B * g.aw[s] * g.ah[s]);
+    }
+    L.carry = carve<float>(base, &off, (size_t)g.w * g.h);
+    L.b.partials = carve<double>(base, &off, g.part_total);
+    L.b.sums_dev = carve<double>(base, &off, B * VK_NSUMS);
+    L.bytes = off;
+    return L;
+}
 }  // namespace
 
 extern "C" {
@@ -854,6 +910,69 @@ int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n
 #undef SVM_TRY
     (void)hipFree(d_sv); (void)hipFree(d_coef); (void)hipFree(d_x); (void)hipFree(d_out);
     return rc;
+}
+
+// ---- the entry point that allocates nothing (scratch area and layout: above, before the extern "C" block) ----
+size_t vmaf_hip_noalloc_scratch_needed(int width, int height, int nframes)
+{
+    if (width < 32 || height < 32 || width > 16384 || height > 16384 || nframes < 1 || nframes > 4096) return 0;
+    Geometry g;
+    geometry_init(&g, width, height, nframes);
+    return noalloc_layout(g, nframes, nullptr).bytes;
+}
+
+int vmaf_hip_extract_device_noalloc(int device, void *stream, const float *d_ref, const float *d_dis, int width, int height,
+                                    size_t row_stride_bytes, size_t frame_stride_bytes, int nframes, int conv_order, double *atoms_out)
+{
+    if (!d_ref || !d_dis || !atoms_out) return fail("null pointer argument");
+    if (width < 32 || height < 32) return fail("frame %dx%d too small (minimum 32x32)", width, height);
+    if (width > 16384 || height > 16384) return fail("frame %dx%d too large", width, height);
+    if (nframes < 1 || nframes > 4096) return fail("nframes %d outside 1..4096", nframes);
+    if (conv_order < 0 || conv_order > 2) return fail("conv order %d is none of 0 (scalar), 1 (avx), 2 (fused multiply-add)", conv_order);
+    if (row_stride_bytes % 4 || frame_stride_bytes % 4) return fail("strides must be multiples of 4 bytes");
+    if (row_stride_bytes < (size_t)width * 4) return fail("row stride %zu smaller than a row", row_stride_bytes);
+    if (nframes > 1 && frame_stride_bytes < row_stride_bytes * height) return fail("frame stride smaller than a frame");
+    if (device < 0 || device >= kMaxDevices) return fail("device %d outside 0..%d", device, kMaxDevices - 1);
+    Geometry g;
+    geometry_init(&g, width, height, nframes);
+    const size_t need = noalloc_layout(g, nframes, nullptr).bytes;
+    if (need > (size_t)VMAF_HIP_NOALLOC_SCRATCH_BYTES)
+        return fail("%d frames of %dx%d need %zu bytes of scratch, the static area holds %zu: pass fewer frames per call or use an engine",
+                    nframes, width, height, need, (size_t)VMAF_HIP_NOALLOC_SCRATCH_BYTES);
+    HIP_TRY(hipSetDevice(device));
+    unsigned char *base = nullptr;
+    if (noalloc_scratch(device, &base)) return 1;
+    const NoallocLayout L = noalloc_layout(g, nframes, base);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rs = (int)(row_stride_bytes / 4);
+    const size_t fs = frame_stride_bytes / 4;
+
+    // the engine's launches, one after the other on the caller's stream.  Nothing in the scratch area has to start at
+    // zero: every workgroup stores its partial sums, reduce_kernel stores every sum, and the pyramid planes are written
+    // before they are read - the previous call's contents are simply overwritten.
+    PlaneCursor vc = { d_ref, d_dis, fs, rs };
+    for (int sc = 0; sc < 4; ++sc)
+        if (launch_vif_scale(&g, &L.b, conv_order, sc, &vc, nframes, s)) return 1;
+    PlaneCursor ac = { d_ref, d_dis, fs, rs };
+    for (int sc = 0; sc < 4; ++sc)
+        if (launch_adm_scale(&g, &L.b, conv_order, sc, &ac, nframes, s)) return 1;
+    HIP_TRY(vk_launch_motion(conv_order, d_ref, fs, rs, width, height, nframes, 0, L.carry, L.carry, L.b.partials + g.part_off_mot, s));
+    vk_reduce_table tab;
+    int q = fill_reduce_table(&g, &tab);
+    for (; q < VK_NSUMS; ++q) tab.d[q] = { 0, 0, 1, 0 };          // optional metrics: not computed here
+    HIP_TRY(vk_launch_reduce(L.b.partials, &tab, nframes, L.b.sums_dev, s));
+
+    // sums -> atoms through a small stack buffer (synchronous copies: atoms_out is complete on return)
+    constexpr int kChunk = 16;
+    double sums[kChunk * VK_NSUMS];
+    for (int f0 = 0; f0 < nframes; f0 += kChunk) {
+        const int n = std::min(kChunk, nframes - f0);
+        HIP_TRY(hipMemcpyAsync(sums, L.b.sums_dev + (size_t)f0 * VK_NSUMS, sizeof(double) * VK_NSUMS * n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int f = 0; f < n; ++f)
+            finish_atoms(&g, sums + (size_t)f * VK_NSUMS, f0 + f > 0, atoms_out + (size_t)(f0 + f) * VMAF_HIP_ATOMS);
+    }
+    return 0;
 }
 
 double vmaf_hip_last_kernel_ms(vmaf_hip_engine *e, int which)
