@@ -57,6 +57,20 @@ double compute_vmaf_raw(char* fmt, int width, int height, int (*read_frame_raw)(
 int compute_vmaf_raw_noexcept(double *score, char* fmt, int width, int height, int (*read_frame_raw)(void *ref_luma, void *main_luma, int stride_byte, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len);
 
 /*
+ * compute_vmaf_raw for sources that can SEEK (regular files): frame-range sharding of one video over several GPUs
+ * (no counterpart in the reference, whose only parallelism is one process per ref/dis pair,
+ * python/src/vmaf/tools/misc.py:246-276).  The caller states the number of frames and hands over a positional callback:
+ * read_frame_raw_at(ref_luma, main_luma, stride_byte, frame_index, user_data) fills the two raw luma planes of frame
+ * `frame_index` (0-based; layout as for compute_vmaf_raw) and returns 0, or non-zero on failure.  It is called from
+ * SEVERAL THREADS AT ONCE - one per device listed in VMAF_HIP_DEVICES ("0,1,..,7"; default "0"; an id may repeat) - each
+ * walking its own contiguous range [g*F/G, (g+1)*F/G) in order, after one extra call for frame start-1 (the motion halo:
+ * the shard blurs that ref frame itself).  Shards exchange nothing; motion2 (vmaf.cpp:375-379) and the fusion run once
+ * after all of them.  Scores, logs and stdout are identical, digit for digit, to compute_vmaf_raw on the same frames.
+ */
+double compute_vmaf_raw_seekable(char* fmt, int width, int height, long nframes, int (*read_frame_raw_at)(void *ref_luma, void *main_luma, int stride_byte, long frame_index, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method);
+int compute_vmaf_raw_seekable_noexcept(double *score, char* fmt, int width, int height, long nframes, int (*read_frame_raw_at)(void *ref_luma, void *main_luma, int stride_byte, long frame_index, void *user_data), void *user_data, char *model_path, char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len);
+
+/*
  * The feature names of a model in model order (model_dict['feature_names'], wrapper/src/vmaf.cpp:79-81), e.g.
  * "VMAF_feature_adm2_score": *n_features = their number D; names_out (may be NULL) receives them separated by '\n',
  * NUL-terminated, when names_len is large enough (otherwise the call fails and *n_features still holds D).

@@ -161,7 +161,8 @@ int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int byt
  * on the planes as given (before the -128 offset), on their own stream next to the VMAF features.  ten_bit selects
  * the PSNR peak and cap (255.75 / 72 instead of 255 / 60, combo.c:171-186).  Call before the first extract, or between
  * synchronised calls.  SSIM at decimation factor 1 (min(w,h) < 384) and MS-SSIM need dense input planes.
- * vmaf_hip_engine_get_metrics copies the metrics of the frames of the last synchronised extract call:
+ * vmaf_hip_engine_get_metrics copies the metrics of the frames of the extract call that was synchronised last (by
+ * vmaf_hip_engine_sync or vmaf_hip_engine_sync_oldest; another call may still be in flight):
  * out[nframes][VMAF_HIP_METRICS] = psnr, ssim, ms_ssim, ansnr, anpsnr (0 where not enabled).
  * vmaf_hip_engine_enable_ansnr adds ANSNR / ANPSNR (feature/src/ansnr.c:44-104, the atoms `ansnr` and `anpsnr` of
  * feature/src/all.c:148-176), computed like every caller of compute_ansnr does on the planes after the -128 offset.

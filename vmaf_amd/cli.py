@@ -182,28 +182,50 @@ class Result:
 
 
 # ---------------------------------------------------------------------------------- scoring
+class LumaFile:
+    """A raw YUV file seen as its luma planes, without reading it: a memory map plus the frame geometry.  The reference
+    reads one frame at a time (feature/src/common/frame.c:26-129: Y plane, then fread-skips the chroma); here a batch of
+    planes is copied out of the map when the GPU is ready for it, so a clip of any length is scored in constant memory."""
+
+    def __init__(self, path, fmt, width, height):
+        self.ten = fmt.endswith('10le')
+        self.w, self.h = width, height
+        n = width * height
+        chroma = {'yuv420p': n // 2, 'yuv422p': n, 'yuv444p': 2 * n}[fmt.replace('10le', '')]
+        self.dtype = np.dtype('<u2') if self.ten else np.dtype(np.uint8)
+        self.n, self.frame_samples = n, n + chroma
+        total = os.path.getsize(path) // self.dtype.itemsize
+        self.frames = total // self.frame_samples
+        if total - self.frames * self.frame_samples >= n:
+            self.frames += 1                               # a last frame with short chroma is still scored (frame.c:83-87)
+        self.mm = np.memmap(path, dtype=self.dtype, mode='r') if total else np.zeros(0, self.dtype)
+
+    def __len__(self):
+        return self.frames
+
+    def planes(self, start, stop, out=None):
+        """Raw luma samples of frames [start, stop) as [n,h,w] (uint8 / uint16), copied into `out[:n]` when given."""
+        n = stop - start
+        if out is None:
+            out = np.empty((n, self.h, self.w), self.dtype)
+        whole = min(stop, len(self.mm) // self.frame_samples)        # frames whose chroma is complete too
+        if whole > start:
+            v = self.mm[start * self.frame_samples:whole * self.frame_samples].reshape(whole - start, self.frame_samples)
+            np.copyto(out[:whole - start].reshape(whole - start, self.n), v[:, :self.n])
+        for f in range(max(whole, start), stop):                     # the truncated last frame
+            out[f - start] = np.asarray(self.mm[f * self.frame_samples:f * self.frame_samples + self.n]).reshape(self.h, self.w)
+        return out[:n]
+
+
 def read_luma(path, fmt, width, height, raw=False):
-    """Memory-map a raw YUV file and return the luma planes [F,h,w], skipping chroma (frame.c:80-124): as float32 in
-    8-bit units (feature/src/common/file_io.c:86-172: 10-bit / 4.0), or with raw=True as the uint8 / uint16 samples
-    themselves, for the GPU to widen (Engine.extract_raw)."""
-    ten = fmt.endswith('10le')
-    n = width * height
-    chroma = {'yuv420p': n // 2, 'yuv422p': n, 'yuv444p': 2 * n}[fmt.replace('10le', '')]
-    dt = np.dtype('<u2') if ten else np.dtype(np.uint8)
-    frame_samples = n + chroma
-    total = os.path.getsize(path) // dt.itemsize
-    frames = total // frame_samples
-    if frames * frame_samples < total and total - frames * frame_samples >= n:
-        frames += 1                                    # a last frame with short chroma is still scored (frame.c:83-87)
-    mm = np.memmap(path, dtype=dt, mode='r')
-    out = np.empty((frames, height, width), (np.uint16 if ten else np.uint8) if raw else np.float32)
-    for f in range(frames):
-        y = np.asarray(mm[f * frame_samples:f * frame_samples + n]).reshape(height, width)
-        if raw:
-            out[f] = y
-        else:
-            out[f] = (y.astype(np.float64) / 4.0).astype(np.float32) if ten else y.astype(np.float32)
-    return out
+    """The luma planes [F,h,w] of a whole raw YUV file, chroma skipped (frame.c:80-124): as float32 in 8-bit units
+    (feature/src/common/file_io.c:86-172: 10-bit / 4.0), or with raw=True as the uint8 / uint16 samples themselves, for
+    the GPU to widen.  For small files (tests, batch-mode pairs); the scorer streams through LumaFile instead."""
+    lf = LumaFile(path, fmt, width, height)
+    y = lf.planes(0, len(lf))
+    if raw:
+        return y
+    return (y.astype(np.float64) / 4.0).astype(np.float32) if lf.ten else y.astype(np.float32)
 
 
 def load_asset(asset):
@@ -212,51 +234,139 @@ def load_asset(asset):
     return read_luma(asset.ref_path, fmt, w, h, raw=True), read_luma(asset.dis_path, fmt, w, h, raw=True)
 
 
+PREFETCH_MAX_PAIR_BYTES = 1 << 30          # pairs larger than this are not loaded ahead: the scorer streams them from their files
+
+
 def prefetched_assets(assets, threads=4, max_bytes=2 << 30):
-    """Yield (asset, (ref, dis)) in order while reader threads load the files of the next assets (up to max_bytes of
-    input ahead): a single thread copies ~8 GB/s out of the page cache, which is what bounds batch mode otherwise."""
+    """Yield (asset, luma) in order while reader threads load the files of the next assets (up to max_bytes of input
+    ahead): a single thread copies ~8 GB/s out of the page cache, which is what bounds batch mode otherwise.  luma =
+    (ref, dis) arrays, or None for a pair too large to hold (score_asset then streams it batch by batch)."""
     from concurrent.futures import ThreadPoolExecutor
+
+    def size(a):
+        try:
+            return os.path.getsize(a.ref_path) + os.path.getsize(a.dis_path)
+        except OSError:
+            return 0
+
     if len(assets) <= 1 or threads <= 1:
         for a in assets:
-            yield a, load_asset(a)
+            yield a, (load_asset(a) if size(a) <= PREFETCH_MAX_PAIR_BYTES else None)
         return
     with ThreadPoolExecutor(max_workers=threads) as pool:
         pending, ahead, nxt = [], 0, 0
-        def size(a):
-            try:
-                return os.path.getsize(a.ref_path) + os.path.getsize(a.dis_path)
-            except OSError:
-                return 0
         while nxt < len(assets) or pending:
             while nxt < len(assets) and (not pending or (len(pending) < 2 * threads and ahead + size(assets[nxt]) <= max_bytes)):
                 a = assets[nxt]
                 w, h, fmt = a.asset_dict['width'], a.asset_dict['height'], a.asset_dict['yuv_type']
-                pending.append((a, size(a), pool.submit(read_luma, a.ref_path, fmt, w, h, True),
-                                pool.submit(read_luma, a.dis_path, fmt, w, h, True)))
+                if size(a) > PREFETCH_MAX_PAIR_BYTES:
+                    pending.append((a, 0, None, None))
+                else:
+                    pending.append((a, size(a), pool.submit(read_luma, a.ref_path, fmt, w, h, True),
+                                    pool.submit(read_luma, a.dis_path, fmt, w, h, True)))
                 ahead += pending[-1][1]
                 nxt += 1
             a, sz, fr, fd = pending.pop(0)
             ahead -= sz
-            yield a, (fr.result(), fd.result())
+            yield a, ((fr.result(), fd.result()) if fr is not None else None)
 
 
-def score_asset(asset, model_path, phone_model, device=0, engine_cache=None, luma=None):
-    """-> Result.  The feature + fusion hot path on the GPU; no CPU fallback."""
+def _batch_size(w, h):
+    return int(min(64, max(4, (128 << 20) // (w * h * 4))))
+
+
+def _stream_range(eng, ref, dis, start, stop, atoms):
+    """Frames [start, stop) of one pair through one engine, streamed: two page-locked batch buffers per file, the copy out
+    of the file map for batch k+1 overlaps the H2D copies and kernels of batch k (two calls in flight).  ref / dis are
+    LumaFile objects or in-memory arrays [F,h,w].  The shard seeds its own motion halo (ref frame start-1)."""
     from . import binding
-    w, h = asset.asset_dict['width'], asset.asset_dict['height']
-    ref, dis = luma if luma is not None else load_asset(asset)
+    if stop <= start:
+        return
+    B = eng.max_batch
+    get = (lambda src, a, b, out: src.planes(a, b, out)) if isinstance(ref, LumaFile) else \
+          (lambda src, a, b, out: (np.copyto(out[:b - a], src[a:b]), out[:b - a])[1])
+    dt = ref.dtype
+    pins = [(binding.PinnedArray((B, eng.h, eng.w), dt), binding.PinnedArray((B, eng.h, eng.w), dt)) for _ in range(2)]
+    try:
+        if start > 0:
+            eng.motion_seed(get(ref, start - 1, start, pins[0][0].array)[0])
+        inflight, k = 0, 0
+        for at in range(start, stop, B):
+            n = min(B, stop - at)
+            if inflight == 2:
+                eng.sync_oldest()
+                inflight -= 1
+            pr, pd = pins[k & 1]
+            eng.extract_host_async(get(ref, at, at + n, pr.array), get(dis, at, at + n, pd.array), atoms[at:at + n], continue_sequence=at > 0)
+            inflight += 1
+            k += 1
+        eng.sync()
+    finally:
+        eng.sync()
+        for pr, pd in pins:
+            pr.close()
+            pd.close()
+
+
+def score_asset(asset, model_path, phone_model, device=0, engine_cache=None, luma=None, devices=None):
+    """-> Result.  The feature + fusion hot path on the GPU; no CPU fallback.  The pair is streamed from its files (or
+    taken from `luma` = (ref, dis) arrays a prefetcher already holds).  devices = [a, b, ..]: contiguous frame ranges of
+    this ONE pair on several GPUs, one host thread + engine per entry (an id may repeat), each with its one-frame motion
+    halo; motion2 and the fusion run once on the merged atoms."""
+    from . import binding, sharding
+    w, h, fmt = asset.asset_dict['width'], asset.asset_dict['height'], asset.asset_dict['yuv_type']
+    if luma is not None:
+        ref, dis = luma
+    else:
+        ref, dis = LumaFile(asset.ref_path, fmt, w, h), LumaFile(asset.dis_path, fmt, w, h)
     frames = min(len(ref), len(dis))
-    key = (w, h, device)
-    eng = engine_cache.get(key) if engine_cache is not None else None
-    if eng is None:
-        batch = int(min(64, max(4, (128 << 20) // (w * h * 4))))
-        eng = binding.Engine(w, h, max_batch=batch, device=device)
-        if engine_cache is not None:
-            engine_cache[key] = eng
-    atoms = eng.extract_raw(ref[:frames], dis[:frames])
+    if frames <= 0:
+        raise binding.VmafHipError(f"no complete frame in {asset.ref_path} / {asset.dis_path}")
+    devices = list(devices) if devices else [device]
+    devices = devices[:frames]
+    atoms = np.zeros((frames, binding.N_ATOMS))
+
+    def engine_for(dev, slot):
+        key = (w, h, dev, slot)
+        eng = engine_cache.get(key) if engine_cache is not None else None
+        if eng is None:
+            eng = binding.Engine(w, h, max_batch=_batch_size(w, h), device=dev)
+            if engine_cache is not None:
+                engine_cache[key] = eng
+        return eng
+
+    if len(devices) == 1:
+        eng = engine_for(devices[0], 0)
+        try:
+            _stream_range(eng, ref, dis, 0, frames, atoms)
+        finally:
+            if engine_cache is None:
+                eng.close()
+    else:
+        import threading
+        errs = []
+
+        def work(g):
+            try:
+                eng = engine_for(devices[g], g)
+                try:
+                    _stream_range(eng, ref, dis, *sharding.frame_range(frames, len(devices), g), atoms)
+                finally:
+                    if engine_cache is None:
+                        eng.close()
+            except BaseException as ex:                           # noqa: BLE001 - re-raised below on the calling thread
+                errs.append(ex)
+
+        th = [threading.Thread(target=work, args=(g,)) for g in range(len(devices))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
     model_path = model_path or binding.DEFAULT_MODEL
     names = binding.model_feature_names(model_path)
-    vm, feats = binding.predict_from_atoms(atoms, model_path, enable_transform=phone_model, device=device)
+    vm, feats = binding.predict_from_atoms(atoms, model_path, enable_transform=phone_model, device=devices[0])
     scores = {name + 's': feats[:, j].tolist() for j, name in enumerate(names)}
     scores['VMAF_scores'] = vm.tolist()
     return Result(asset, scores)
@@ -307,7 +417,8 @@ def run_vmaf_main(argv):
     phone_model = _flag(argv, 6, '--phone-model')
     cid = zlib.crc32(_stem(ref_file).encode()) % (10 ** 16)
     asset = Asset("cmd", cid, cid, ref_file, dis_file, width, height, fmt)
-    result = score_asset(asset, model_path, phone_model)
+    # VMAF_HIP_DEVICES="0,1,..": contiguous frame ranges of this one pair on several GPUs (default: device 0)
+    result = score_asset(asset, model_path, phone_model, devices=_device_list() if os.environ.get("VMAF_HIP_DEVICES", "").strip() else [0])
     result.set_pool(pool_method)
     _print_result(result, out_fmt)
     return 0

@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/libvmaf.h"
@@ -71,10 +72,15 @@ struct FrameSource {
     int bps = 0;
     int (*read_frame)(float *, float *, float *, int, void *) = nullptr;
     int (*read_raw)(void *, void *, int, void *) = nullptr;
+    // seekable source (compute_vmaf_raw_seekable): frame `index` of nframes, callable from several threads at once
+    int (*read_raw_at)(void *, void *, int, long, void *) = nullptr;
+    long nframes = 0;
     void *user = nullptr;
 };
 
 struct MetricFlags { bool psnr = false, ssim = false, ms_ssim = false, ten_bit = false; bool any() const { return psnr || ssim || ms_ssim; } };
+
+int batch_frames(size_t plane);
 
 void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, const MetricFlags &mf, std::vector<double> &atoms,
                    std::vector<double> &metrics /* [frames][VMAF_HIP_METRICS] when mf.any() */)
@@ -87,8 +93,7 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, cons
     const int G = (int)devices.size();
     // frames per batch: ~32 MB of luma per plane and batch (16 frames of raw 8-bit 1080p).  Larger batches only add
     // page-locked memory to set up and latency before the first launch; measured with tools/e2e_cli_rate.py
-    int batch = (int)std::min<size_t>(64, std::max<size_t>(4, ((size_t)32 << 20) / plane));
-    if (const char *env = std::getenv("VMAF_HIP_BATCH")) { const int v = std::atoi(env); if (v > 0) batch = std::min(v, 4096); }
+    const int batch = batch_frames(plane);
 
     EngineGuard guard;
     struct Slot { float *ref[2], *dis[2]; int fill = 0; bool pending = false; size_t pend_start = 0; int pend_n = 0; std::vector<double> out; };
@@ -165,6 +170,99 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, cons
     for (int i = 0; i < G; ++i) collect(i);
     atoms.resize(total * kAtoms);
     if (mf.any()) metrics.resize(total * VMAF_HIP_METRICS);
+}
+
+int batch_frames(size_t plane)
+{
+    // frames per batch: ~32 MB of luma per plane and batch (16 frames of raw 8-bit 1080p), see extract_atoms
+    int batch = (int)std::min<size_t>(64, std::max<size_t>(4, ((size_t)32 << 20) / plane));
+    if (const char *env = std::getenv("VMAF_HIP_BATCH")) { const int v = std::atoi(env); if (v > 0) batch = std::min(v, 4096); }
+    return batch;
+}
+
+// One contiguous frame range [start, stop) of a seekable source on one engine: the shard
+// reads and blurs ref frame start-1 itself (motion halo: ref only, no VIF/ADM), then walks its range in double-buffered
+// batches - the reads of batch k+1 overlap the copies and kernels of batch k.  Writes atoms[start..stop).
+void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar_order, const MetricFlags &mf, long start, long stop,
+                   double *atoms, double *metrics)
+{
+    const size_t stride = (size_t)w * src.bps, plane = stride * h;
+    const int batch = batch_frames(plane);
+    EngineGuard guard;
+    vmaf_hip_engine *e = nullptr;
+    if (vmaf_hip_engine_create(&e, device, w, h, batch)) throw VmafException(vmaf_hip_last_error());
+    guard.engines.push_back(e);
+    static const bool fast = std::getenv("VMAF_HIP_FAST") && std::atoi(std::getenv("VMAF_HIP_FAST")) != 0;
+    if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1)) throw VmafException(vmaf_hip_last_error());
+    if (mf.any() && vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit)) throw VmafException(vmaf_hip_last_error());
+    char *ref[2], *dis[2];
+    for (int b = 0; b < 2; ++b) {
+        char **pp[2] = { &ref[b], &dis[b] };
+        for (auto p : pp) {
+            *p = (char *)vmaf_hip_host_alloc(plane * batch);
+            if (!*p) throw VmafException(vmaf_hip_last_error());
+            guard.pinned.push_back(*p);
+        }
+    }
+    auto read = [&](char *r, char *d, long frame) {
+        const int ret = src.read_raw_at(r, d, (int)stride, frame, src.user);
+        if (ret) throw VmafException("read_frame failed at frame " + std::to_string(frame) + ".");
+    };
+    if (start > 0) {
+        read(ref[0], dis[0], start - 1);
+        if (vmaf_hip_motion_seed_host_raw(e, ref[0], src.bps, stride)) throw VmafException(vmaf_hip_last_error());
+    }
+    std::vector<double> out[2];
+    out[0].resize((size_t)batch * kAtoms); out[1].resize((size_t)batch * kAtoms);
+    struct Pend { long at = 0; int n = 0; } pend[2];
+    int inflight = 0, fill = 0;
+    auto collect = [&]() {                                         // oldest call in flight -> atoms / metrics rows
+        const int b = (fill + 2 - inflight) % 2;
+        if (vmaf_hip_engine_sync_oldest(e)) throw VmafException(vmaf_hip_last_error());
+        std::copy(out[b].begin(), out[b].begin() + (size_t)pend[b].n * kAtoms, atoms + (size_t)pend[b].at * kAtoms);
+        if (mf.any() && vmaf_hip_engine_get_metrics(e, metrics + (size_t)pend[b].at * VMAF_HIP_METRICS, pend[b].n))
+            throw VmafException(vmaf_hip_last_error());
+        --inflight;
+    };
+    for (long at = start; at < stop; at += batch) {
+        const int n = (int)std::min<long>(batch, stop - at);
+        if (inflight == 2) collect();                              // frees buffer `fill`
+        for (int i = 0; i < n; ++i) read(ref[fill] + plane * i, dis[fill] + plane * i, at + i);
+        if (vmaf_hip_extract_host_raw_async(e, ref[fill], dis[fill], src.bps, stride, plane, n, at > 0 ? 1 : 0, out[fill].data()))
+            throw VmafException(vmaf_hip_last_error());
+        pend[fill] = { at, n };
+        ++inflight;
+        fill ^= 1;
+    }
+    while (inflight) collect();
+}
+
+// Frame-range sharding of ONE video over the devices of VMAF_HIP_DEVICES: device g scores frames [g*F/G, (g+1)*F/G) on its
+// own host thread with its own engine and reads; no exchange between shards (the halo is re-read), motion2 and the fusion
+// run after all shards have delivered (vmaf.cpp:375-379 needs motion[i+1] across the shard edge).
+void extract_atoms_sharded(const FrameSource &src, int w, int h, bool scalar_order, const MetricFlags &mf, std::vector<double> &atoms,
+                           std::vector<double> &metrics)
+{
+    if (w <= 0 || h <= 0) throw VmafException("wrong width " + std::to_string(w) + " or height " + std::to_string(h) + ".");
+    const long F = src.nframes;
+    if (F <= 0) throw VmafException("no frames delivered by read_frame");
+    std::vector<int> devices = parse_devices();
+    if ((long)devices.size() > F) devices.resize((size_t)F);
+    const int G = (int)devices.size();
+    atoms.assign((size_t)F * kAtoms, 0.0);
+    if (mf.any()) metrics.assign((size_t)F * VMAF_HIP_METRICS, 0.0);
+    std::vector<std::string> errors(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        const long start = F * g / G, stop = F * (g + 1) / G;
+        th.emplace_back([&, g, start, stop] {
+            try { extract_shard(src, devices[g], w, h, scalar_order, mf, start, stop, atoms.data(), mf.any() ? metrics.data() : nullptr); }
+            catch (const std::exception &ex) { errors[g] = ex.what(); if (errors[g].empty()) errors[g] = "unknown error"; }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; ++g)
+        if (!errors[g].empty()) throw VmafException(errors[g]);
 }
 
 const char *kKnownFeatures[] = { "adm2", "adm_scale0", "adm_scale1", "adm_scale2", "adm_scale3", "motion", "vif_scale0",
@@ -324,7 +422,7 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
 {
     std::printf("Start calculating VMAF score...\n");             // vmaf.cpp:638
     if (!model_path) throw VmafException("Error loading model (.pkl): null path");
-    if (!(src.bps ? (void *)src.read_raw : (void *)src.read_frame)) throw VmafException("read_frame callback is null");
+    if (!(src.read_raw_at ? (void *)src.read_raw_at : src.bps ? (void *)src.read_raw : (void *)src.read_frame)) throw VmafException("read_frame callback is null");
 
     vmaf_amd::VmafModel model;
     try { model = vmaf_amd::load_vmaf_model(model_path); }
@@ -337,7 +435,8 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
     const size_t fl = fmt ? std::strlen(fmt) : 0;
     mf.ten_bit = fl > 4 && std::strcmp(fmt + fl - 4, "10le") == 0;   // combo.c:171-186: the PSNR peak follows the format
     std::vector<double> metrics;
-    extract_atoms(src, width, height, disable_avx, mf, atoms, metrics);
+    if (src.read_raw_at) extract_atoms_sharded(src, width, height, disable_avx, mf, atoms, metrics);
+    else extract_atoms(src, width, height, disable_avx, mf, atoms, metrics);
     const size_t F = atoms.size() / kAtoms;
     if (F == 0) throw VmafException("no frames delivered by read_frame");
     std::vector<double> vmaf;
@@ -394,6 +493,39 @@ double compute_vmaf_raw(char *fmt, int width, int height, int (*read_frame_raw)(
     src.read_raw = read_frame_raw; src.user = user_data;
     return run_vmaf(fmt, width, height, src, model_path, log_path, log_fmt, disable_clip != 0, disable_avx != 0,
                     (enable_transform || phone_model), do_psnr != 0, do_ssim != 0, do_ms_ssim != 0, pool_method);
+}
+
+double compute_vmaf_raw_seekable(char *fmt, int width, int height, long nframes,
+                                 int (*read_frame_raw_at)(void *, void *, int, long, void *), void *user_data, char *model_path, char *log_path,
+                                 char *log_fmt, int disable_clip, int disable_avx, int enable_transform, int phone_model, int do_psnr,
+                                 int do_ssim, int do_ms_ssim, char *pool_method)
+{
+    FrameSource src;
+    const size_t n = fmt ? std::strlen(fmt) : 0;
+    src.bps = (n > 4 && std::strcmp(fmt + n - 4, "10le") == 0) ? 2 : 1;
+    src.read_raw_at = read_frame_raw_at; src.nframes = nframes; src.user = user_data;
+    if (!read_frame_raw_at) throw VmafException("read_frame callback is null");
+    return run_vmaf(fmt, width, height, src, model_path, log_path, log_fmt, disable_clip != 0, disable_avx != 0,
+                    (enable_transform || phone_model), do_psnr != 0, do_ssim != 0, do_ms_ssim != 0, pool_method);
+}
+
+int compute_vmaf_raw_seekable_noexcept(double *score, char *fmt, int width, int height, long nframes,
+                                       int (*read_frame_raw_at)(void *, void *, int, long, void *), void *user_data, char *model_path,
+                                       char *log_path, char *log_fmt, int disable_clip, int disable_avx, int enable_transform,
+                                       int phone_model, int do_psnr, int do_ssim, int do_ms_ssim, char *pool_method, char *errbuf, int errbuf_len)
+{
+    try {
+        const double s = compute_vmaf_raw_seekable(fmt, width, height, nframes, read_frame_raw_at, user_data, model_path, log_path, log_fmt,
+                                                   disable_clip, disable_avx, enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, pool_method);
+        if (score) *score = s;
+        return 0;
+    } catch (const std::exception &e) {
+        copy_err(errbuf, errbuf_len, e.what());
+        return 1;
+    } catch (...) {
+        copy_err(errbuf, errbuf_len, "unknown error");
+        return 1;
+    }
 }
 
 int compute_vmaf_raw_noexcept(double *score, char *fmt, int width, int height, int (*read_frame_raw)(void *, void *, int, void *),

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -51,7 +52,6 @@ public:
         jobs_ = nullptr;
     }
 
-private:
     static void do_read(Job &j)
     {
         j.got = 0;
@@ -62,6 +62,7 @@ private:
             j.got += r;
         }
     }
+private:
     Job *take()
     {
         std::lock_guard<std::mutex> l(m_);
@@ -100,11 +101,9 @@ struct YuvPair {
     bool ten_bit = false;
     size_t chroma_samples = 0;          // samples to skip after each luma plane (main.cpp:69-86)
     std::vector<unsigned char> row;
-    // pooled reading (both files regular): positions are tracked here, the FILE* positions are not used
-    ReadPool *pool = nullptr;
-    int chunks = 1;                     // pread chunks per plane
-    off_t ref_off = 0, dis_off = 0;
-    std::vector<ReadPool::Job> jobs;
+    // regular files (compute_vmaf_raw_seekable): frames are read by position, from several shard threads at once
+    size_t luma_bytes = 0, frame_bytes = 0;
+    int threads_per_shard = 1;
 };
 
 // One luma plane -> fp32 in 8-bit units (10-bit: value / 4.0, file_io.c:159-163). 0 ok, 1 short read.
@@ -157,26 +156,6 @@ int read_frame_raw_cb(void *ref_luma, void *dis_luma, int stride_byte, void *use
 {
     YuvPair &s = *(YuvPair *)user;
     const size_t bytes = (size_t)stride_byte * s.height;
-    if (s.pool) {
-        // regular files: both planes as pread chunks on the pool; same outcome rules as below (frame.c:48-78: a short luma
-        // read is end of stream = 2 or failure = 1, ref checked first; the chroma planes are skipped by position only, so
-        // a last frame with truncated chroma is still scored, frame.c:83-87,127-128)
-        const size_t per = (bytes + s.chunks - 1) / s.chunks;
-        s.jobs.clear();
-        for (int f = 0; f < 2; ++f)
-            for (size_t o = 0; o < bytes; o += per)
-                s.jobs.push_back({ fileno(f ? s.dis : s.ref), (char *)(f ? dis_luma : ref_luma) + o, std::min(per, bytes - o),
-                                   (f ? s.dis_off : s.ref_off) + (off_t)o, 0 });
-        s.pool->run(s.jobs);
-        for (size_t i = 0; i < s.jobs.size(); ++i) {               // ref chunks first, in file order
-            if (s.jobs[i].got < 0) return 1;
-            if ((size_t)s.jobs[i].got != s.jobs[i].n) return 2;
-        }
-        const off_t step = (off_t)bytes + (off_t)(s.chroma_samples * (s.ten_bit ? 2 : 1));
-        s.ref_off += step;
-        s.dis_off += step;
-        return 0;
-    }
     // the two files are read side by side: one copy from the page cache into page-locked memory per thread is what
     // bounds the file-to-score rate of this CLI
     int dis_rc = 0;
@@ -194,6 +173,40 @@ int read_frame_raw_cb(void *ref_luma, void *dis_luma, int stride_byte, void *use
     }
     t.join();
     return ref_rc ? ref_rc : dis_rc;                             // frame.c:48-78: the ref read is checked first
+}
+
+// Positional form for regular files (compute_vmaf_raw_seekable): the luma planes of frame `index`, each as a few pread()
+// chunks side by side on the calling shard's own little pool of reader threads (made on first use, ended with the
+// shard's thread).  Called concurrently from one thread per shard; touches no shared state but the two descriptors.
+int read_frame_raw_at_cb(void *ref_luma, void *dis_luma, int stride_byte, long index, void *user)
+{
+    const YuvPair &s = *(const YuvPair *)user;
+    const size_t bytes = (size_t)stride_byte * s.height;
+    if (bytes != s.luma_bytes) return 1;
+    thread_local std::unique_ptr<ReadPool> pool;
+    thread_local std::vector<ReadPool::Job> jobs;
+    if (!pool && s.threads_per_shard > 1) pool.reset(new ReadPool(s.threads_per_shard - 1));     // the shard's thread reads too
+    const int chunks = std::max(1, s.threads_per_shard / 2);
+    const size_t per = (bytes + chunks - 1) / chunks;
+    const off_t at = (off_t)index * (off_t)s.frame_bytes;
+    jobs.clear();
+    for (int f = 0; f < 2; ++f)
+        for (size_t o = 0; o < bytes; o += per)
+            jobs.push_back({ fileno(f ? s.dis : s.ref), (char *)(f ? dis_luma : ref_luma) + o, std::min(per, bytes - o), at + (off_t)o, 0 });
+    if (pool) pool->run(jobs);
+    else for (auto &j : jobs) ReadPool::do_read(j);
+    for (auto &j : jobs)
+        if (j.got < 0 || (size_t)j.got != j.n) return 1;           // the frame count was taken from the file sizes: a short read is a failure
+    return 0;
+}
+
+// Frames a raw YUV file of `size` bytes holds under the reference's rule (frame.c:48-87): a frame counts when its luma
+// plane is complete; its chroma may be cut short.
+long frames_in(off_t size, size_t luma_bytes, size_t frame_bytes)
+{
+    long n = (long)(size / (off_t)frame_bytes);
+    if ((size_t)(size - (off_t)n * (off_t)frame_bytes) >= luma_bytes) ++n;
+    return n;
 }
 
 const char *opt_value(char **b, char **e, const std::string &name)
@@ -257,18 +270,28 @@ int main(int argc, char *argv[])
     int ret = 0;
     if (!(s.ref = std::fopen(ref_path, "rb"))) { std::fprintf(stderr, "fopen ref_path %s failed.\n", ref_path); ret = 1; }
     else if (!(s.dis = std::fopen(dis_path, "rb"))) { std::fprintf(stderr, "fopen ref_path %s failed.\n", dis_path); ret = 1; }
-    ReadPool *pool = nullptr;
+    bool seekable = false;
+    long nframes = 0;
     if (!ret) {
-        // reader threads when both inputs are regular files (VMAF_HIP_READ_THREADS, default 8; 0 or 1 = off)
+        // regular files are read by position: reader threads (VMAF_HIP_READ_THREADS, default 8; 0 or 1 = the shard's own
+        // thread only), and frame-range shards over the devices of VMAF_HIP_DEVICES.  Pipes and FIFOs keep the
+        // sequential path.  VMAF_HIP_SEEKABLE=0 forces the sequential path for files too.
         struct stat sr, sd;
         const char *env = std::getenv("VMAF_HIP_READ_THREADS");
         int nthreads = env ? std::atoi(env) : 8;
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && nthreads > hw) nthreads = hw;
-        if (nthreads > 1 && fstat(fileno(s.ref), &sr) == 0 && fstat(fileno(s.dis), &sd) == 0 && S_ISREG(sr.st_mode) && S_ISREG(sd.st_mode)) {
-            pool = new ReadPool(nthreads - 1);                   // the calling thread reads too
-            s.pool = pool;
-            s.chunks = std::max(1, nthreads / 2);
+        const char *sk = std::getenv("VMAF_HIP_SEEKABLE");
+        const bool allow = !(sk && *sk == '0');
+        if (allow && fstat(fileno(s.ref), &sr) == 0 && fstat(fileno(s.dis), &sd) == 0 && S_ISREG(sr.st_mode) && S_ISREG(sd.st_mode)) {
+            const size_t bps = s.ten_bit ? 2 : 1;
+            s.luma_bytes = n * bps;
+            s.frame_bytes = (n + s.chroma_samples) * bps;
+            nframes = std::min(frames_in(sr.st_size, s.luma_bytes, s.frame_bytes), frames_in(sd.st_size, s.luma_bytes, s.frame_bytes));
+            int shards = 1;
+            if (const char *dv = std::getenv("VMAF_HIP_DEVICES")) shards = 1 + (int)std::count(dv, dv + std::strlen(dv), ',');
+            s.threads_per_shard = std::max(1, nthreads / std::max(1, shards));
+            seekable = nframes > 0;                              // an empty pair takes the sequential path and its error message
         }
     }
     if (!ret) {
@@ -277,6 +300,9 @@ int main(int argc, char *argv[])
             if (fp32 && *fp32 && *fp32 != '0')
                 compute_vmaf(fmt, width, height, read_frame_cb, &s, model_path, (char *)log_path, (char *)log_fmt, disable_clip, disable_avx,
                              enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
+            else if (seekable)
+                compute_vmaf_raw_seekable(fmt, width, height, nframes, read_frame_raw_at_cb, &s, model_path, (char *)log_path, (char *)log_fmt,
+                                          disable_clip, disable_avx, enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
             else
                 compute_vmaf_raw(fmt, width, height, read_frame_raw_cb, &s, model_path, (char *)log_path, (char *)log_fmt, disable_clip,
                                  disable_avx, enable_transform, phone_model, do_psnr, do_ssim, do_ms_ssim, (char *)pool_method);
@@ -286,7 +312,6 @@ int main(int argc, char *argv[])
             ret = -1;
         }
     }
-    delete pool;
     if (s.ref) std::fclose(s.ref);
     if (s.dis) std::fclose(s.dis);
     return ret;

@@ -638,7 +638,6 @@ int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes)
 {
     if (!e || !out) return fail("null argument");
     if (!(e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr)) return fail("no metric enabled on this engine");
-    if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (nframes < 0 || (size_t)nframes * VMAF_HIP_METRICS > e->metrics.size()) return fail("the last call scored %zu frames, %d asked for", e->metrics.size() / VMAF_HIP_METRICS, nframes);
     std::copy(e->metrics.begin(), e->metrics.begin() + (size_t)nframes * VMAF_HIP_METRICS, out);
     return 0;
