@@ -23,6 +23,15 @@ int vmaf_hip_engine_debug_read_plane(vmaf_hip_engine *e, int kind, int level, in
                                      int *width, int *height);
 
 /*
+ * The raw fp64 device sums of one frame of the LAST synchronised extract call, before the host rounds them into the
+ * atoms the way the reference does ((float) casts, powf, ...): out[0..7] VIF num, den of scale 0..3, out[8..31] ADM cube
+ * sums (scale s: num h,v,d, den h,v,d), out[32] motion SAD.  The kernels accumulate their per-pixel fp32 values in fp64,
+ * so these pin every pixel's value against an oracle that sums the same values exactly (oracle_vif_exact_sums).
+ */
+#define VMAF_HIP_DEBUG_SUMS 33
+int vmaf_hip_engine_debug_read_sums(vmaf_hip_engine *e, int frame, double *out);
+
+/*
  * Kernel-level timing hook for bench.py: HIP-event time in milliseconds of the LAST extract call's
  * kernels, measured on the engine's own stream.  which: 0 = whole batch, 1 = VIF scale-0 statistic
  * kernel (the dominant kernel).  Returns < 0 when nothing has run.

@@ -10,6 +10,6 @@ and only as the checker.  The product (vmaf_amd) must never import it.
 from .binding import (lib, ref_lib, ref_exec_path, ORDER_SCALAR, ORDER_AVX, ATOM_NAMES,  # noqa: F401
                       conv_sep, vif, adm, sad, frame, clip_atoms, ref_conv_sep, ref_vif,
                       ref_adm, ref_frame, ref_clip_atoms, ref_svm_predict, csf_rfactors,
-                      psnr, ssim, ms_ssim, ref_psnr, ref_ssim, ref_ms_ssim, ansnr, ref_ansnr, vif_pyramid, adm_ll_pyramid)
+                      psnr, ssim, ms_ssim, ref_psnr, ref_ssim, ref_ms_ssim, ansnr, ref_ansnr, vif_pyramid, adm_ll_pyramid, vif_exact_sums)
 from .fusion import (load_pkl_model, load_svm_model, svm_predict, vmaf_from_atoms,     # noqa: F401
                      derived_features)

@@ -44,6 +44,7 @@ def lib():
         L.oracle_conv_sep.argtypes = [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oracle_conv_sep.restype = None
         L.oracle_vif.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        L.oracle_vif_exact_sums.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         L.oracle_adm.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
         L.oracle_sad.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oracle_sad.restype = C.c_double
@@ -132,6 +133,16 @@ def vif(ref_off, dis_off, order=ORDER_SCALAR):
                           sc.ctypes.data_as(_dp))
     assert rc == 0
     return s.value, n.value, dn.value, sc
+
+
+def vif_exact_sums(ref_off, dis_off, order=ORDER_SCALAR):
+    """-> [8] sums of the per-pixel VIF num / den values of scales 0..3 in extended precision (planes already offset)."""
+    r, d = _f32(ref_off), _f32(dis_off)
+    h, w = r.shape
+    out = np.zeros(8)
+    rc = lib().oracle_vif_exact_sums(_ptr(r), _ptr(d), w, h, w, order, out.ctypes.data_as(_dp))
+    assert rc == 0
+    return out
 
 
 def adm(ref_off, dis_off, exact_rcp=0):

@@ -163,8 +163,27 @@ static float sum_rows_then_total(const float *x, int w, int h, int stride)
     return total;
 }
 
+static int vif_impl(const float *ref, const float *dis, int w, int h, int stride, int order,
+                    double *score, double *score_num, double *score_den, double scores[8], double exact[8]);
+
 int oracle_vif(const float *ref, const float *dis, int w, int h, int stride, int order,
                double *score, double *score_num, double *score_den, double scores[8])
+{
+    return vif_impl(ref, dis, w, h, stride, order, score, score_num, score_den, scores, NULL);
+}
+
+/* Test aid, no counterpart in the reference: the per-pixel num / den values of vif_statistic_s (bit-identical to the
+ * reference's, see tests/test_oracle_vs_ref.py) summed in extended precision instead of vif_sum_s's fp32 row-then-total
+ * order.  exact[2s], exact[2s+1] = sum of num, den of scale s, correct to ~1e-16 relative: what a GPU kernel that
+ * accumulates the same per-pixel values in fp64 must reproduce to ~1e-12, i.e. a pin on EVERY pixel's value. */
+int oracle_vif_exact_sums(const float *ref, const float *dis, int w, int h, int stride, int order, double exact[8])
+{
+    double s, n, d, sc[8];
+    return vif_impl(ref, dis, w, h, stride, order, &s, &n, &d, sc, exact);
+}
+
+static int vif_impl(const float *ref, const float *dis, int w, int h, int stride, int order,
+                    double *score, double *score_num, double *score_den, double scores[8], double exact[8])
 {
     size_t n0 = (size_t)w * h;
     float *buf = (float *)malloc(sizeof(float) * n0 * 12);
@@ -235,6 +254,12 @@ int oracle_vif(const float *ref, const float *dis, int w, int h, int stride, int
         }
         scores[2 * s] = sum_rows_then_total(num, w, h, w);            /* vif.c:265-269 */
         scores[2 * s + 1] = sum_rows_then_total(den, w, h, w);
+        if (exact) {
+            long double en = 0.0L, ed = 0.0L;
+            for (size_t p = 0; p < (size_t)w * h; ++p) { en += num[p]; ed += den[p]; }
+            exact[2 * s] = (double)en;
+            exact[2 * s + 1] = (double)ed;
+        }
     }
 
     double tn = 0, td = 0;                                            /* vif.c:277-291 */

@@ -50,6 +50,9 @@ double oracle_sad(const float *a, const float *b, int w, int h, int a_stride, in
 int oracle_frame(const float *ref_raw, const float *dis_raw, int w, int h, int stride,
                  float *prev_blur, int first_frame, int order, double *atoms);
 
+/* Test aid: the same per-pixel num / den values summed in extended precision (exact[2s], exact[2s+1]). */
+int oracle_vif_exact_sums(const float *ref_off, const float *dis_off, int w, int h, int stride, int order, double exact[8]);
+
 /* The filter tables (vif_tools.c:82-97, motion_tools.h:24-29) for tests that want them. */
 const float *oracle_vif_filter(int scale, int *width);
 const float *oracle_motion_filter(void);

@@ -92,8 +92,39 @@ def run_exec(fmt, w, h, ref_path, dis_path, model, extra):
     return {"stdout_score": float(m.group(2)), "pool": m.group(1), "aggregate_xml": float(agg), "frames": frames}
 
 
+LOG_CASES = ["default", "phone", "harmonic", "tenbit", "metrics", "noclip", "vmafv4"]
+
+
+def exec_logs():
+    """exec_logs.json: the TEXT the reference's vmafossexec wrote for a few EXEC cases - stdout, the XML log
+    (wrapper/src/vmaf.cpp:719-750, pugixml number style) and the JSON log (vmaf.cpp:679-717, ptools JSONPrint number
+    style, values rounded to 5 digits) - so that the formatting itself is pinned, not only the values."""
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name in LOG_CASES:
+            clip, fmt, model, extra = EXEC[name]
+            r, d, bits = clip_arrays(clip)
+            rp, dp = os.path.join(td, "ref.yuv"), os.path.join(td, "dis.yuv")
+            synth.write_yuv(rp, r, fmt)
+            synth.write_yuv(dp, d, fmt)
+            F, h, w = r.shape
+            res = {}
+            for log_fmt in ("xml", "json"):
+                log = os.path.join(td, "log." + log_fmt)
+                p = subprocess.run([oracle.ref_exec_path(), fmt, str(w), str(h), rp, dp, os.path.join(ROOT, model), "--log", log,
+                                    "--log-fmt", log_fmt] + extra, capture_output=True, text=True, check=True)
+                res[log_fmt] = open(log).read()
+                res["stdout"] = p.stdout
+            out[name] = res
+    json.dump(out, open(os.path.join(HERE, "exec_logs.json"), "w"), indent=0)
+    print("wrote exec_logs.json")
+
+
 def main():
     assert oracle.ref_lib() is not None and oracle.ref_exec_path(), "run `make -C oracle ref ref_exec` first"
+    if "--logs-only" in sys.argv:
+        exec_logs()
+        return
     atoms = {}
     for name in CLIPS:
         r, d, bits = clip_arrays(name)
@@ -146,6 +177,7 @@ def main():
         sv[model] = {"x": x.tolist(), "y": oracle.ref_svm_predict(os.path.join(ROOT, model), x).tolist()}
     json.dump(sv, open(os.path.join(HERE, "svm.json"), "w"), indent=0)
     print("wrote atoms.json exec.json svm.json")
+    exec_logs()
 
 
 if __name__ == "__main__":

@@ -84,6 +84,38 @@ def test_reference_main_runs_on_this_library(name, tmp_path):
     _check_against_golden(stdout, xml, case)
 
 
+LOGS = json.load(open(os.path.join(GOLD, "exec_logs.json")))
+_NUM = re.compile(r"-?\d+(?:\.\d+)?(?:[eE][-+]?\d+)?")
+
+
+def _same_text_up_to_numbers(ours, ref, what):
+    """Token for token: everything that is not a number must be the same bytes (element and attribute names, order,
+    quoting, indentation, line breaks); numbers must agree within the parity tolerances (features 1e-4, scores 1e-3, plus
+    the rounding step of the log format) and whole numbers must be PRINTED the same way ("0" in the XML, "0.0" in the
+    JSON log - pugixml's and ptools' number styles)."""
+    mask = lambda t: re.sub(r'(execFps="|Exec FPS: )[^"\n]*', r"\1#", t)     # noqa: E731 - run time is not content
+    ours, ref = mask(ours), mask(ref)
+    assert _NUM.sub("#", ours) == _NUM.sub("#", ref), what
+    for a, b in zip(_NUM.findall(ours), _NUM.findall(ref)):
+        va, vb = float(a), float(b)
+        if vb == int(vb):
+            assert a == b, (what, a, b)
+        else:
+            assert abs(va - vb) <= (2e-4 if abs(vb) < 2 else 1.5e-3), (what, a, b)
+
+
+@pytest.mark.parametrize("name", sorted(LOGS))
+def test_log_text_matches_the_reference_token_for_token(name, tmp_path):
+    """tests/golden/exec_logs.json holds what the reference's vmafossexec printed and logged (make_golden.py) as TEXT:
+    pins the writers of wrapper/src/vmaf.cpp:664-750, number formatting included."""
+    case, want = EXEC[name], LOGS[name]
+    stdout, xml = _run(OURS, case, tmp_path, "xml")
+    _same_text_up_to_numbers(stdout, want["stdout"], f"{name} stdout")
+    _same_text_up_to_numbers(xml, want["xml"], f"{name} xml")
+    _, js = _run(OURS, case, tmp_path, "json")
+    _same_text_up_to_numbers(js, want["json"], f"{name} json")
+
+
 def test_json_log_schema(tmp_path):
     case = EXEC["default"]
     _, text = _run(OURS, case, tmp_path, "json")

@@ -56,6 +56,87 @@ def test_atoms_match_oracle(w, h, frames, order):
     _check(got, want, f"{w}x{h} {order}")
 
 
+# A fixed slice of tools/fuzz_parity.py's sweep: sizes that straddle the tile pitches of the kernels (VIF 48x32 tiles in
+# 8-row waves, ADM 61x14 interior coefficients = 122x28 pixels, motion 60x32) and the 8-column blocks of the AVX order,
+# both orders, 8 and 10 bit, through the raw-luma ingest.
+FUZZ_CASES = [(47, 33, 8, "avx", 1), (48, 32, 8, "scalar", 2), (49, 65, 10, "avx", 2), (60, 61, 8, "avx", 3), (61, 60, 8, "scalar", 1),
+              (95, 97, 8, "avx", 2), (96, 96, 10, "scalar", 2), (97, 95, 8, "avx", 1), (121, 57, 8, "avx", 2), (122, 56, 8, "scalar", 2),
+              (123, 57, 10, "avx", 1), (244, 56, 8, "avx", 2), (245, 113, 8, "scalar", 1), (32, 32, 8, "avx", 3), (257, 131, 10, "avx", 2),
+              (419, 299, 8, "scalar", 2)]
+
+
+@pytest.mark.parametrize("w,h,bits,order,frames", FUZZ_CASES)
+def test_sizes_around_the_tile_pitches(w, h, bits, order, frames):
+    r, d = synth.make_clip(w, h, frames, bits=bits, seed=1000 * w + h)
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    want = oracle.clip_atoms(ref, dis, ORDERS[order])
+    with vmaf_amd.Engine(w, h, max_batch=2, order=order) as e:
+        got = e.extract_raw(r, d)
+    assert np.all(np.isfinite(got))
+    _check(got, want, f"{w}x{h} {bits}-bit {order}")
+
+
+@pytest.mark.parametrize("order", ["avx", "scalar"])
+@pytest.mark.parametrize("w,h", [(240, 135), (480, 270), (720, 68), (240, 33), (960, 540)])
+def test_wide_tile_kernel_on_noisy_pairs(w, h, order):
+    """Planes whose width is a multiple of 240 take the workgroup-wide VIF tiles (vif_stat_wg_kernel: four waves side by
+    side, edge strips redone per pixel).  Strong noise makes VIF's sigma^2 = E[x^2] - mu^2 cancellation amplify any
+    sample that took the wrong summation order (the reference's two orders are ~5e-5 apart in the features on such
+    content), so the 2e-6 bound on the raw sums pins the order of every region: top / bottom rows, the first and last
+    8 columns, heights that are not a multiple of the 8-row tiles, one tile per row (w = 240: both edge strips in it)."""
+    ref, dis = _clip(w, h, 2, seed=w * 7 + h, dis_noise=25, quant=24)
+    want = oracle.clip_atoms(ref, dis, ORDERS[order])
+    with vmaf_amd.Engine(w, h, max_batch=2, order=order) as e:
+        got = e.extract(ref, dis)
+        _check(got, want, f"{w}x{h} {order}")
+        for kind, plane in (("vif_ref", ref[1]), ("vif_dis", dis[1])):     # next-scale planes from the wide tiles: bit for bit
+            for lvl, want_plane in enumerate(oracle.vif_pyramid(plane + np.float32(-128), ORDERS[order]), start=1):
+                assert np.array_equal(e.debug_plane(kind, lvl, 1), want_plane), (kind, lvl)
+
+
+EXACT_RTOL = 2e-12
+
+
+@pytest.mark.parametrize("order", ["avx", "scalar"])
+@pytest.mark.parametrize("w,h", [(240, 321), (480, 321), (481, 321), (96, 64), (250, 37)])
+def test_every_vif_pixel_is_pinned_through_the_fp64_sums(golden_dir, order, w, h):
+    """The VIF kernels add their per-pixel fp32 num / den values in fp64; the oracle can add the same values in extended
+    precision (oracle.vif_exact_sums).  If every pixel's value is bit-identical, the two sums agree to ~1e-14; a single
+    region in the wrong summation order (a few hundred pixels, each off by one fp32 rounding) moves them by >= 1e-11.
+    Crops of tests/golden/images/100007 (the pair on which the reference's own two orders end up 3.7e-3 VMAF apart):
+    widths 240 / 480 run the workgroup-wide tiles (edge strips, top / bottom rows), 481 / 96 / 250 the wave-private tiles
+    with their border frame.  The opposite order must miss the bound, or the test would prove nothing."""
+    ref = np.fromfile(os.path.join(golden_dir, "images", "100007.yuv"), np.uint8)[:481 * 321].reshape(321, 481)[:h, :w].astype(np.float32)
+    dis = np.fromfile(os.path.join(golden_dir, "images", "100007_noisy.yuv"), np.uint8)[:481 * 321].reshape(321, 481)[:h, :w].astype(np.float32)
+    ref, dis = np.ascontiguousarray(ref), np.ascontiguousarray(dis)
+    off = np.float32(-128)
+    want = oracle.vif_exact_sums(ref + off, dis + off, ORDERS[order])
+    other = oracle.vif_exact_sums(ref + off, dis + off, ORDERS["scalar" if order == "avx" else "avx"])
+    with vmaf_amd.Engine(w, h, order=order) as e:
+        e.extract(ref[None], dis[None])
+        got = e.debug_sums(0)[:8]
+    rel = np.abs(got - want) / np.abs(want)
+    assert np.all(rel < EXACT_RTOL), (rel, got, want)
+    assert np.max(np.abs(got - other) / np.abs(other)) > 50 * EXACT_RTOL
+
+
+@pytest.mark.parametrize("order", ["avx", "scalar"])
+@pytest.mark.parametrize("w,h,bits", [(1920, 1080, 8), (960, 540, 10), (1280, 720, 8), (720, 203, 8)])
+def test_every_vif_pixel_is_pinned_at_the_benchmark_sizes(w, h, bits, order):
+    """The same pin (fp64 device sums against the oracle's exact sums of its per-pixel values, 2e-12) at BASELINE.json's
+    frame sizes: 1920x1080 and its pyramid run the workgroup-wide tiles, 1280x720 the wave-private ones."""
+    r, d = synth.make_clip(w, h, 1, bits=bits, seed=w + 3 * h, dis_noise=12)
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    off = np.float32(-128)
+    want = oracle.vif_exact_sums(ref[0] + off, dis[0] + off, ORDERS[order])
+    other = oracle.vif_exact_sums(ref[0] + off, dis[0] + off, ORDERS["scalar" if order == "avx" else "avx"])
+    with vmaf_amd.Engine(w, h, order=order) as e:
+        e.extract(ref, dis)
+        got = e.debug_sums(0)[:8]
+    assert np.all(np.abs(got - want) / np.abs(want) < EXACT_RTOL), (got, want)
+    assert np.max(np.abs(got - other) / np.abs(other)) > 50 * EXACT_RTOL
+
+
 def test_noisy_image_where_the_two_orders_diverge(golden_dir):
     """tests/golden/images/100007: the reference's own AVX and scalar paths differ by 3.7e-3 VMAF on this pair
     (65.415667 vs 65.412008); the engine has to land on the right one in each mode."""

@@ -64,6 +64,7 @@ def load_library():
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_engine_sync_oldest.argtypes = [vp]
     L.vmaf_hip_engine_debug_read_plane.argtypes = [vp, i, i, i, _fp, sz, C.POINTER(i), C.POINTER(i)]
+    L.vmaf_hip_engine_debug_read_sums.argtypes = [vp, i, _dp]
     L.vmaf_hip_host_alloc.argtypes = [sz]
     L.vmaf_hip_host_alloc.restype = vp
     L.vmaf_hip_host_free.argtypes = [vp]
@@ -251,6 +252,13 @@ class Engine:
         if self.L.vmaf_hip_engine_debug_read_plane(self._h, k, level, frame, buf.ctypes.data_as(_fp), buf.size, C.byref(w), C.byref(h)):
             raise VmafHipError(_err(self.L))
         return buf[:w.value * h.value].reshape(h.value, w.value).copy()
+
+    def debug_sums(self, frame=0):
+        """Raw fp64 device sums of one frame of the last synchronised call (include/vmaf_hip_debug.h) -> [33]."""
+        out = np.zeros(33)
+        if self.L.vmaf_hip_engine_debug_read_sums(self._h, frame, out.ctypes.data_as(_dp)):
+            raise VmafHipError(_err(self.L))
+        return out
 
     def sync_oldest(self):
         """Finish the oldest of the (at most two) asynchronous extract calls in flight."""

@@ -671,6 +671,15 @@ int vmaf_hip_engine_debug_read_plane(vmaf_hip_engine *e, int kind, int level, in
     return 0;
 }
 
+int vmaf_hip_engine_debug_read_sums(vmaf_hip_engine *e, int frame, double *out)
+{
+    if (!e || !out) return fail("null argument");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
+    if (frame < 0 || frame >= e->max_batch) return fail("frame %d outside the batch", frame);
+    std::copy(e->sums_host[e->last_slot] + (size_t)frame * VK_NSUMS, e->sums_host[e->last_slot] + (size_t)frame * VK_NSUMS + VMAF_HIP_DEBUG_SUMS, out);
+    return 0;
+}
+
 int vmaf_hip_engine_sync_oldest(vmaf_hip_engine *e)
 {
     if (!e) return fail("null engine");

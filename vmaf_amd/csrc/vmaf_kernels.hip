@@ -538,6 +538,229 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_
     }
 }
 
+// ---------------------------------------------------------------- VIF, workgroup-wide tiles
+// Same arithmetic as vif_wave_tile, other work distribution, for planes whose width is a multiple of 240 (every level of
+// the 1080p and 4K pyramids).  A wave-private 48-column tile spends a third of its vertical pass on halo columns
+// (64 filtered columns per 48 outputs at 17 taps); here the four waves of a workgroup stand side by side on 256 columns
+// and share the vertical results through LDS: 256 filtered columns per 240 outputs.
+//   vertical pass     thread = one of the 256 columns x0-R .. ; its 8+2R input rows from global memory, {r, d, r^2, d^2, rd}
+//                     x 8 rows in registers; the vertical half of the next scale's decimation from the same windows
+//   horizontal pass   thread = (row, strip of 8 columns): 8 x 30 = 240 of the 256 threads; planes through LDS in rounds of 3,
+//                     row pitch 258 = 2 mod 32 and a thread order that puts 4 rows x 4 strips into every group of 16 lanes:
+//                     the 16 lanes a ds_read_b64 serves per cycle touch 32 different banks
+//   ORDER_AVX         rows pick their order per output (uniform over the workgroup); horizontally only the first and the
+//                     last 8 columns of a plane ever leave the vector order (w % 8 == 0 here): those two EDGE STRIPS are
+//                     redone by one wave, one pixel per lane, in the order convolution_f32_avx_s_1d takes per sample,
+//                     instead of making a whole wave evaluate both orders for every output
+constexpr int VWG_TW = 240, VWG_TH = 8, VWG_COLS = 256, VWG_P = 258, VWG_HS = 8, VWG_STRIPS = VWG_TW / VWG_HS;
+static_assert(VWG_COLS == VIF_THREADS && VWG_TW + 16 == VWG_COLS && VWG_P % 32 == 2, "one thread per filtered column; pitch 2 mod 32");
+
+template <int FW> struct VifWgGeom {
+    static constexpr int R = FW / 2;
+    static constexpr int NV = VWG_HS + 2 * R;                  // window of one horizontal item
+    static constexpr int DFW = FW == 17 ? 9 : FW == 9 ? 5 : FW == 5 ? 3 : 0;
+    static constexpr int RD = DFW / 2;
+    static constexpr int DVW = VWG_TW + 2 * RD;                // columns the decimation's vertical pass keeps
+    static constexpr int DP = 250;                             // its row pitch
+    static constexpr int DSH = 4;                              // decimated outputs per thread: 2 planes x 4 rows x 30 strips = 240 threads
+    static constexpr int VQ = 3;
+    static constexpr int V_FLOATS = VQ * VWG_TH * VWG_P;
+    static constexpr int D_FLOATS = DFW ? 2 * (VWG_TH / 2) * DP : 0;
+    static_assert(NV % 2 == 0 && DVW <= DP && VWG_TW + 2 * R <= VWG_COLS, "float2 reads; planes fit");
+};
+
+// horizontal item of a thread: 4 rows x 4 strips per 16 lanes (see above); threads 224..239 take the last two strips
+__device__ __forceinline__ void vwg_item(int tid, int &row, int &strip)
+{
+    if (tid < 224) {
+        const int g = tid >> 4, in = tid & 15;
+        strip = (g >> 1) * 4 + (in & 3);
+        row = (g & 1) * 4 + (in >> 2);
+    } else {
+        strip = 28 + (tid & 1);
+        row = (tid >> 1) & 7;
+    }
+}
+
+template <int FW, bool OFFSET, int ORDER>
+__global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_kernel(VIF_KERNEL_PARAMS)
+{
+    using G = VifWgGeom<FW>;
+    constexpr int R = G::R, P = VWG_P, DFW = G::DFW, RD = G::RD, DVW = G::DVW, DP = G::DP;
+    constexpr int NW = VWG_TH + 2 * R;
+    __shared__ __attribute__((aligned(16))) float smem[G::V_FLOATS + G::D_FLOATS];
+    __shared__ double red[2 * (VIF_THREADS / 64)];
+    float *vout = smem, *dv_s = smem + G::V_FLOATS;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntx = w / VWG_TW;
+    const int ntiles = gridDim.x;
+    const int tile_id = xcd_tile_index();
+    const int tx = tile_id % ntx;
+    const int x0 = tx * VWG_TW, y0 = (tile_id / ntx) * VWG_TH;
+    const float *fr = ref + (size_t)blockIdx.z * frame_stride;
+    const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+    double acc[2] = { 0.0, 0.0 };
+
+    // ---- vertical pass: thread = column x0 - R + tid
+    float vo[5][VWG_TH];
+    const int vc = tid;
+    const bool vlane = vc < VWG_TW + 2 * R;                    // FW < 17 needs fewer than 256 columns
+    const int gxc = mirror_idx(x0 - R + vc, w);
+    {
+        float rv[NW], dv[NW], t[NW];
+        const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
+        const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int roff = mirror_idx(y0 - R + i, h) * row_stride * 4;           // workgroup-uniform: SGPR
+            rv[i] = buf_load(br, gxc * 4, roff);
+            dv[i] = buf_load(bd, gxc * 4, roff);
+        }
+        if (OFFSET) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { rv[i] = rv[i] + -128.0f; dv[i] = dv[i] + -128.0f; }   // offset_image, combo.c:236-237
+        }
+        if (DFW > 0) {
+            // decimation, vertical pass at the even rows (y0 is even): output row y0 + 2i is window element R + 2i.
+            // w % 8 == 0: every column is in the vector order of the vertical pass (convolution_avx.c:806-815)
+            const bool dcol = vc >= R - RD && vc < R - RD + DVW;
+#pragma unroll
+            for (int i = 0; i < VWG_TH / 2; ++i) {
+                const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + 2 * i, h, RD);
+                const float a = taps_sel<DFW ? DFW : 3, false, ORDER>(rv + R - RD + 2 * i, 1, avx);
+                const float b = taps_sel<DFW ? DFW : 3, false, ORDER>(dv + R - RD + 2 * i, 1, avx);
+                if (dcol) {
+                    dv_s[i * DP + vc - (R - RD)] = a;
+                    dv_s[(VWG_TH / 2 + i) * DP + vc - (R - RD)] = b;
+                }
+            }
+        }
+        unsigned vmask = 0;                                    // ORDER_AVX: vector order in the rows r <= y < h - r
+        if (ORDER == ORDER_AVX) {
+#pragma unroll
+            for (int o = 0; o < VWG_TH; ++o) vmask |= avx_row_ok(y0 + o, h, R) ? 1u << o : 0u;
+        }
+#define VWG_VPASS(src, q)                                                          \
+        if (ORDER == ORDER_AVX) taps_window_sel<FW, VWG_TH>(src, vo[q], vmask);    \
+        else taps_window<FW, VWG_TH, ORDER>(src, vo[q])
+        VWG_VPASS(rv, 0);
+        VWG_VPASS(dv, 1);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t[i] = rv[i] * rv[i];
+        VWG_VPASS(t, 2);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t[i] = dv[i] * dv[i];
+        VWG_VPASS(t, 3);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t[i] = rv[i] * dv[i];
+        VWG_VPASS(t, 4);
+#undef VWG_VPASS
+    }
+
+    // ---- horizontal pass
+    int row, strip;
+    vwg_item(tid, row, strip);
+    const bool hlane = tid < VWG_TH * VWG_STRIPS;
+    // edge strips (ORDER_AVX only): columns [0, 8) of the plane and [w - 8, w); one wave each, lane = (row, column)
+    const int hend = avx_hcol_end(w, R);
+    const bool edge_l = ORDER == ORDER_AVX && tx == 0, edge_r = ORDER == ORDER_AVX && tx == ntx - 1;
+    const bool edge_wave = (edge_l && wv == 0) || (edge_r && wv == 1);          // wave-uniform
+    const int lane = tid & 63;
+    const int erow = lane & 7, ecol = (wv == 0 ? 0 : VWG_TW - VWG_HS) + (lane >> 3);   // column inside the tile
+    float ho[5][VWG_HS], he[5];
+#pragma unroll
+    for (int round = 0; round < (5 + G::VQ - 1) / G::VQ; ++round) {
+        constexpr int VQ = G::VQ;
+        const int q0 = round * VQ, nq = 5 - q0 < VQ ? 5 - q0 : VQ;
+        if (round > 0) __syncthreads();                        // the previous round's reads are done
+        if (vlane) {
+#pragma unroll
+            for (int q = 0; q < VQ; ++q)
+                if (q < nq) {
+#pragma unroll
+                    for (int o = 0; o < VWG_TH; ++o) vout[(q * VWG_TH + o) * P + vc] = vo[q0 + q][o];
+                }
+        }
+        __syncthreads();
+        if (round == 0 && DFW > 0) {
+            // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes; thread = (plane, output
+            // row, strip of 4 outputs): a row of a tile leaves as 120 consecutive floats, one 16-byte store per thread
+            constexpr int DSH = G::DSH, DNW = 2 * (DSH - 1) + (DFW ? DFW : 1);
+            if (tid < 2 * (VWG_TH / 2) * (VWG_TW / 2 / DSH)) {
+                const int ds = tid % (VWG_TW / 2 / DSH), dr = (tid / (VWG_TW / 2 / DSH)) & 3, pl = tid / (4 * (VWG_TW / 2 / DSH));
+                const int ox0 = ds * DSH;
+                const int oh = h / 2, dend = avx_hcol_end(w, RD);
+                const float *src = dv_s + (pl * (VWG_TH / 2) + dr) * DP + 2 * ox0;
+                float dw[DNW], val[DSH];
+#pragma unroll
+                for (int k = 0; k < DNW; ++k) dw[k] = src[k];
+#pragma unroll
+                for (int o = 0; o < DSH; ++o) {
+                    const int sx = x0 + 2 * (ox0 + o);
+                    val[o] = taps_sel<DFW ? DFW : 3, false, ORDER>(dw + 2 * o, 1, ORDER == ORDER_AVX && sx >= RD && sx < dend);
+                }
+                const int gyd = y0 / 2 + dr;
+                if (gyd < oh) {
+                    float *dst = (pl ? odis : oref) + (size_t)blockIdx.z * out_frame_stride + (size_t)gyd * out_row_stride + x0 / 2 + ox0;
+                    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < DSH; ++o) dst[o] = val[o];
+                    }
+                }
+            }
+        }
+        if (hlane) {
+#pragma unroll
+            for (int q = 0; q < VQ; ++q)
+                if (q < nq) {
+                    float v[G::NV];
+                    const float2 *p = reinterpret_cast<const float2 *>(vout + (q * VWG_TH + row) * P + strip * VWG_HS);
+#pragma unroll
+                    for (int m = 0; m < G::NV / 2; ++m) {
+                        const float2 f2 = p[m];
+                        v[2 * m] = f2.x; v[2 * m + 1] = f2.y;
+                    }
+                    taps_window<FW, VWG_HS, ORDER>(v, ho[q0 + q]);
+                }
+        }
+        if (edge_wave) {
+            const int gx = x0 + ecol;
+            const bool avx = gx >= R && gx < hend;
+#pragma unroll
+            for (int q = 0; q < VQ; ++q)
+                if (q < nq) {
+                    float v[FW];
+                    const float *p = vout + (q * VWG_TH + erow) * P + ecol;
+#pragma unroll
+                    for (int k = 0; k < FW; ++k) v[k] = p[k];
+                    he[q0 + q] = taps_sel<FW, false, ORDER_AVX>(v, 1, avx);
+                }
+        }
+    }
+    if (hlane) {
+        const int gy = y0 + row;
+        const bool in_edge = (edge_l && strip == 0) || (edge_r && strip == VWG_STRIPS - 1);
+        if (gy < h && !in_edge) {
+#pragma unroll
+            for (int o = 0; o < VWG_HS; ++o) {
+                float n, d;
+                vif_pixel(ho[0][o], ho[1][o], ho[2][o], ho[3][o], ho[4][o], n, d);
+                acc[0] += (double)n; acc[1] += (double)d;
+            }
+        }
+    }
+    if (edge_wave && y0 + erow < h) {
+        float n, d;
+        vif_pixel(he[0], he[1], he[2], he[3], he[4], n, d);
+        acc[0] += (double)n; acc[1] += (double)d;
+    }
+    const size_t tile = (size_t)blockIdx.z * ntiles + tile_id;
+    block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
+}
+
 // ---------------------------------------------------------------- ADM
 // One workgroup = ADM_SW x ADM_SH coefficient slots (a ADM_TW x ADM_TH interior plus the one-coefficient halo the
 // masking threshold looks at), 256 threads, no staging of the input picture:
@@ -1273,7 +1496,19 @@ inline dim3 grid_flat(int w, int h, int tw, int th, int nframes) { return dim3((
 // ---------------------------------------------------------------- launchers
 extern "C" {
 
-int vk_vif_tiles(int w, int h) { return ((w + VIF_TW - 1) / VIF_TW) * ((h + VIF_TH - 1) / VIF_TH); }
+// Planes whose width is a multiple of 240 (and of 8: no scalar-order columns but the two edge strips) take the
+// workgroup-wide tiles of vif_stat_wg_kernel; every other size the wave-private 48x32 tiles.  VMAF_HIP_VIF_WG=0 turns
+// the wide tiles off (A/B measurements).
+static bool vif_use_wg(int w, int h)
+{
+    static const int env = getenv("VMAF_HIP_VIF_WG") ? atoi(getenv("VMAF_HIP_VIF_WG")) : 1;
+    return env != 0 && w >= VWG_TW && w % VWG_TW == 0 && h >= 17;
+}
+int vk_vif_tiles(int w, int h)
+{
+    if (vif_use_wg(w, h)) return (w / VWG_TW) * ((h + VWG_TH - 1) / VWG_TH);
+    return ((w + VIF_TW - 1) / VIF_TW) * ((h + VIF_TH - 1) / VIF_TH);
+}
 int vk_adm_tiles(int w, int h)
 {
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
@@ -1291,8 +1526,14 @@ hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const floa
     const int nb = bg.ntiles, ni = (bg.tx_r - 1) * (bg.ty_b - 1), nb_pad = ni > 0 ? (nb + 7) / 8 * 8 : nb;
     const dim3 gm(nb_pad + ni, 1, nframes);                   // border-frame tiles (padded) first, then the interior rectangle
 #define VIF_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+    const bool wg = vif_use_wg(w, h);
+    const dim3 gw(wg ? vk_vif_tiles(w, h) : 1, 1, nframes);
 #define VIF_STAT(FW, OFF)                                                                              \
-    if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
+    if (wg) {                                                                                          \
+        if (order == ORDER_SCALAR) vif_stat_wg_kernel<FW, OFF, ORDER_SCALAR><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
+        else if (order == ORDER_FMA) vif_stat_wg_kernel<FW, OFF, ORDER_FMA><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
+        else vif_stat_wg_kernel<FW, OFF, ORDER_AVX><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);              \
+    } else if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
     else if (order == ORDER_FMA) vif_stat_kernel<FW, OFF, ORDER_FMA><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
     else vif_stat_avx_kernel<FW, OFF><<<gm, VIF_THREADS, 0, s>>>(VIF_ARGS, nb_pad)
     switch (scale) {
