@@ -7,7 +7,8 @@
 Workload (BASELINE.json configs[1]): synthetic 1920x1080 yuv420p 8-bit ref/dis pair, luma resident in
 HBM as fp32 (what a read_frame callback delivers) before the timed region starts.  A step = one batch of
 FRAMES_PER_STEP consecutive frames through the whole hot path (120: 30 distinct synthetic frames tiled four times in HBM,
-every one of them scored); default 50 steps x 120 frames = 6000 frames.
+every one of them scored); default 300 steps x 120 frames = 36 000 frames (a timed region of about a second, long
+enough for an outside GPU-utilisation sampler to see it).
 Multi-GPU: contiguous frame ranges per rank with a one-frame motion halo (weak scaling: every rank gets
 steps x 120 frames), per-frame atom rows gathered to rank 0 over RCCL, SVR fusion for all frames on rank 0 -
 all inside the timed region.
@@ -185,7 +186,7 @@ def end_to_end(r8, d8, order, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory / CLI figures reported beside the headline")
@@ -330,7 +331,8 @@ def main():
         if kernel_ms:
             achieved = VIF0_BYTES_PER_PX * W * H * B / (kernel_ms * 1e-3) / 1e9
             prof = committed_profile(B) if args.order == "avx" else {}     # the committed counters are of the default order
-            roof = {"bound": "hbm", "kernel": "vif_stat_avx_kernel<17> (VIF scale 0, fused; border-frame + interior tiles in one launch)" if args.order == "avx" else f"vif_stat_kernel<17> ({args.order} order)",
+            roof = {"bound": "hbm", "kernel": (f"vif_stat_wg_kernel<17> (VIF scale 0, fused, workgroup-wide 240x8 tiles; {args.order} order)" if W % 240 == 0 else
+                               f"vif_stat_avx_kernel<17> / vif_stat_kernel<17> (VIF scale 0, fused, wave-private 48x32 tiles; {args.order} order)"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": prof.get("traffic"), "algorithmic_bytes": int(VIF0_BYTES_PER_PX * W * H * B),
                     "launch_ms": round(kernel_ms, 4), "frames_per_launch": B,

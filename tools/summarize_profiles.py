@@ -63,6 +63,9 @@ def main():
             wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
             wr.writeheader()
             wr.writerows(rows)
+    met = glob.glob(os.path.join(src, "stats_metrics", "**", "*kernel_stats.csv"), recursive=True)
+    if met:
+        shutil.copy(met[0], os.path.join(dst, f"{tag}_kernel_stats_metrics.csv"))
     ser = glob.glob(os.path.join(src, "stats_serial", "**", "*kernel_stats.csv"), recursive=True)
     dur = {}
     if ser:
@@ -85,8 +88,10 @@ def main():
                 d = dur.get(k)
                 frac = round(row[0] * 2 / (1024 * d * 1e-9 * 2.4e9), 3) if d else ""
                 wr.writerow([k, round(d / 1e3, 1) if d else ""] + [int(x) for x in row] + [frac])
-    # the dominant kernel = VIF scale 0 = vif_stat_avx_kernel<17, true> (border-frame + interior tiles in one launch)
-    dom = [r for r in rows if r["kernel"].startswith("vif_stat_avx_kernel<17")]
+    # the dominant kernel = VIF scale 0: vif_stat_wg_kernel<17, true, 1> at widths that are multiples of 240 (1080p, 4K),
+    # else vif_stat_avx_kernel<17, true>
+    # (third template argument 1 = the reference's AVX order, the default; 2 = the opt-in fused order of bench.py's fast_mode leg)
+    dom = [r for r in rows if r["kernel"] == "vif_stat_wg_kernel<17, true, 1>"] or [r for r in rows if r["kernel"].startswith("vif_stat_avx_kernel<17")]
     if dom:
         valu = sum(cnt["SQ_INSTS_VALU"].get(r["kernel"], (0.0, 0))[0] for r in dom)
         json.dump({"source": f"profiles/{tag}_hbm_traffic.csv, profiles/{tag}_valu_counters.csv",
