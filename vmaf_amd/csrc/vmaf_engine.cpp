@@ -294,13 +294,13 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
             } else if (rs != e->w || fs != (size_t)e->w * e->h) {
                 return fail("ssim at decimation factor 1 needs dense input planes");
             }
-            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, e->partials + e->part_off_ssim, q));
+            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, 0, e->partials + e->part_off_ssim, q));
         }
         if (e->m_ms) {
             if (rs != e->w || fs != (size_t)e->w * e->h) return fail("ms_ssim needs dense input planes");
             const float *cr0 = d_ref, *cd0 = d_dis;
             for (int i = 0; i < 5; ++i) {
-                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, e->partials + e->part_off_ms[i], q));
+                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, i < 4 ? 1 : 0, e->partials + e->part_off_ms[i], q));   // ms_ssim.c:62-64: alpha = 0 below the last level
                 if (i < 4) {
                     HIP_TRY(vk_launch_lpf_decimate(cr0, cd0, (size_t)e->ms_w[i] * e->ms_h[i], e->ms_w[i], e->ms_w[i], e->ms_h[i],
                                                    e->ms_ref[i + 1], e->ms_dis[i + 1], e->ms_w[i + 1], e->ms_h[i + 1], nframes, q));

@@ -59,7 +59,8 @@ hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src
 int vk_ansnr_tiles(int w, int h);
 hipError_t vk_launch_ansnr(const float *ref, const float *dis, size_t frame_stride, int row_stride, int w, int h, int nframes,
                            double *partial, hipStream_t s);
-hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, double *partial, hipStream_t s);
+// cs_only: only the contrast and structure sums (MS-SSIM levels whose luminance exponent is 0)
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, double *partial, hipStream_t s);
 hipError_t vk_launch_reduce(const double *partial, const vk_reduce_table *tab, int nframes, double *sums, hipStream_t s);
 hipError_t vk_launch_svm(const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho, const double *x,
                          int n, double *out, hipStream_t s);

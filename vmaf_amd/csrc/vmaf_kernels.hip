@@ -1213,72 +1213,128 @@ __global__ __launch_bounds__(256) void box_decimate_kernel(const float *__restri
     dst[((size_t)blockIdx.z * sh + y) * sw + x] = (float)sum;
 }
 
-// ms_ssim.c:41-51: 9/7 biorthogonal low-pass, the 2-D table _iqa_decimate applies (81 taps, row-major)
-constexpr float kLpf9[81] = {
-     0.000714f,-0.000450f,-0.002090f, 0.007132f, 0.016114f, 0.007132f,-0.002090f,-0.000450f, 0.000714f,
-    -0.000450f, 0.000283f, 0.001316f,-0.004490f,-0.010146f,-0.004490f, 0.001316f, 0.000283f,-0.000450f,
-    -0.002090f, 0.001316f, 0.006115f,-0.020867f,-0.047149f,-0.020867f, 0.006115f, 0.001316f,-0.002090f,
-     0.007132f,-0.004490f,-0.020867f, 0.071207f, 0.160885f, 0.071207f,-0.020867f,-0.004490f, 0.007132f,
-     0.016114f,-0.010146f,-0.047149f, 0.160885f, 0.363505f, 0.160885f,-0.047149f,-0.010146f, 0.016114f,
-     0.007132f,-0.004490f,-0.020867f, 0.071207f, 0.160885f, 0.071207f,-0.020867f,-0.004490f, 0.007132f,
-    -0.002090f, 0.001316f, 0.006115f,-0.020867f,-0.047149f,-0.020867f, 0.006115f, 0.001316f,-0.002090f,
-    -0.000450f, 0.000283f, 0.001316f,-0.004490f,-0.010146f,-0.004490f, 0.001316f, 0.000283f,-0.000450f,
-     0.000714f,-0.000450f,-0.002090f, 0.007132f, 0.016114f, 0.007132f,-0.002090f,-0.000450f, 0.000714f,
+// ms_ssim.c:41-51: 9/7 biorthogonal low-pass, the 2-D table _iqa_decimate applies (81 float taps, row-major),
+// widened to double and kept in memory: the kernel row loop is not unrolled and fetches its 9 coefficients through the
+// scalar cache (81 double literals would not fit the SGPR file and end up in VGPRs)
+__device__ const double kLpf9D[81] = {
+#define L9(x) (double)x##f
+     L9(0.000714),L9(-0.000450),L9(-0.002090), L9(0.007132), L9(0.016114), L9(0.007132),L9(-0.002090),L9(-0.000450), L9(0.000714),
+    L9(-0.000450), L9(0.000283), L9(0.001316),L9(-0.004490),L9(-0.010146),L9(-0.004490), L9(0.001316), L9(0.000283),L9(-0.000450),
+    L9(-0.002090), L9(0.001316), L9(0.006115),L9(-0.020867),L9(-0.047149),L9(-0.020867), L9(0.006115), L9(0.001316),L9(-0.002090),
+     L9(0.007132),L9(-0.004490),L9(-0.020867), L9(0.071207), L9(0.160885), L9(0.071207),L9(-0.020867),L9(-0.004490), L9(0.007132),
+     L9(0.016114),L9(-0.010146),L9(-0.047149), L9(0.160885), L9(0.363505), L9(0.160885),L9(-0.047149),L9(-0.010146), L9(0.016114),
+     L9(0.007132),L9(-0.004490),L9(-0.020867), L9(0.071207), L9(0.160885), L9(0.071207),L9(-0.020867),L9(-0.004490), L9(0.007132),
+    L9(-0.002090), L9(0.001316), L9(0.006115),L9(-0.020867),L9(-0.047149),L9(-0.020867), L9(0.006115), L9(0.001316),L9(-0.002090),
+    L9(-0.000450), L9(0.000283), L9(0.001316),L9(-0.004490),L9(-0.010146),L9(-0.004490), L9(0.001316), L9(0.000283),L9(-0.000450),
+     L9(0.000714),L9(-0.000450),L9(-0.002090), L9(0.007132), L9(0.016114), L9(0.007132),L9(-0.002090),L9(-0.000450), L9(0.000714),
+#undef L9
 };
-constexpr int LPF_TW = 32, LPF_TH = 8, LPF_IW = 2 * LPF_TW + 8, LPF_IH = 2 * LPF_TH + 7;   // staged 72 x 23
+constexpr int LPF_TW = 64, LPF_TH = 16, LPF_OPT = 4;                       // outputs per workgroup, outputs per thread (one row)
+constexpr int LPF_IW = 2 * LPF_TW + 8, LPF_IH = 2 * LPF_TH + 7;            // staged 136 x 39 samples
+constexpr int LPF_NW = 2 * (LPF_OPT - 1) + 9;                               // a thread's window per kernel row: 15 samples
+constexpr int LPF_GP = 12;                                                  // LDS: every group of 8 samples is followed by 4 floats of padding:
+constexpr int LPF_RP = (LPF_IW / 8) * LPF_GP;                               // neighbouring threads' windows then start 48 bytes apart and the
+                                                                            // float4 reads of 8 lanes cover all 32 banks
+static_assert(LPF_TH * (LPF_TW / LPF_OPT) == 256 && LPF_IW % 8 == 0 && LPF_NW <= 16, "thread = (output row, strip of 4 outputs)");
 
-// ms_ssim.c:250-266: one level of the pyramid, both planes of a frame pair handled by blockIdx.z = 2*frame + plane
-__global__ __launch_bounds__(256) void lpf_decimate_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+// ms_ssim.c:250-266: one level of the pyramid, both planes of a frame pair handled by blockIdx.z = 2*frame + plane.
+// _iqa_decimate -> _iqa_filter_pixel (iqa/convolve.c:219-268): sum over the 9x9 table in row-major order of img * k, the
+// product rounded to float, the sum kept in double, the result stored as float.  As in ssim_taps the terms enter the double
+// sum through v_fma_f64 (exact products; see there); a thread forms four neighbouring outputs of a row from one 16-sample
+// window per kernel row (widened once) instead of 9 samples per output.
+__global__ __launch_bounds__(256, 4) void lpf_decimate_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                            size_t src_frame_stride, int src_row_stride, int w, int h,
                                                            float *__restrict__ oref, float *__restrict__ odis, int sw, int sh)
 {
-    __shared__ float tile[LPF_IH * LPF_IW];
+    __shared__ __attribute__((aligned(16))) float tile[LPF_IH * LPF_RP];
     const int frame = blockIdx.z >> 1, plane = blockIdx.z & 1;
     const float *img = (plane ? dis : ref) + (size_t)frame * src_frame_stride;
     float *out = (plane ? odis : oref) + (size_t)frame * sw * sh;
     const int x0 = blockIdx.x * LPF_TW, y0 = blockIdx.y * LPF_TH;
-    {   // every global load of a thread is in flight before its first LDS write (one memory round trip per tile)
-        constexpr int N = LPF_IH * LPF_IW, IT = (N + 255) / 256;
-        float a[IT];
+    {   // staging: thread = one of the first 128 tile columns x every second tile row; the row offset is wave-uniform
+        // (an SGPR), the mirrored column index is computed once (buffer loads, as in the feature kernels).  All loads of a
+        // thread are in flight before its first LDS write.
+        const int tid = threadIdx.x;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 7), lx = tid & 127;
+        const auto br = frame_rsrc(img, (unsigned)h * (unsigned)src_row_stride * 4u);
+        const int gx = sym_idx(2 * x0 - 4 + lx, w);
+        constexpr int NR = (LPF_IH + 1) / 2;
+        float a[NR];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            if (idx < N) {
-                const int ly = idx / LPF_IW, lx = idx - ly * LPF_IW;
-                a[it] = img[(size_t)sym_idx(2 * y0 - 4 + ly, h) * src_row_stride + sym_idx(2 * x0 - 4 + lx, w)];
+        for (int i = 0; i < NR; ++i) {
+            const int ly = 2 * i + half;
+            a[i] = buf_load(br, gx * 4, sym_idx(2 * y0 - 4 + ly, h) * src_row_stride * 4);   // ly == LPF_IH (half = 1, last i): a valid row, not stored
+        }
+        // the last 8 columns of the tile: 39 x 8 samples, one or two per thread
+        float e[2];
+        int epos[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j;
+            epos[j] = -1;
+            e[j] = 0.0f;
+            if (idx < LPF_IH * 8) {
+                const int ly = idx >> 3, ex = 128 + (idx & 7);
+                e[j] = img[(size_t)sym_idx(2 * y0 - 4 + ly, h) * src_row_stride + sym_idx(2 * x0 - 4 + ex, w)];
+                epos[j] = ly * LPF_RP + (ex >> 3) * LPF_GP + (ex & 7);
             }
         }
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            if (idx < N) tile[idx] = a[it];
+        for (int i = 0; i < NR; ++i) {
+            const int ly = 2 * i + half;
+            if (ly < LPF_IH) tile[ly * LPF_RP + (lx >> 3) * LPF_GP + (lx & 7)] = a[i];
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (epos[j] >= 0) tile[epos[j]] = e[j];
     }
     __syncthreads();
-    const int ox = threadIdx.x & 31, oy = threadIdx.x >> 5;
-    double sum = 0.0;
+    const int oy = threadIdx.x >> 4, seg = threadIdx.x & 15, ox0 = seg * LPF_OPT;
+    double sum[LPF_OPT] = {};
+#pragma unroll 1
+    for (int v = 0; v < 9; ++v) {
+        double win[16];
+        // samples 8*seg .. 8*seg + 15 of the tile row = groups seg and seg + 1
+        const float4 *src = reinterpret_cast<const float4 *>(tile + (2 * oy + v) * LPF_RP + seg * LPF_GP);
 #pragma unroll
-    for (int v = 0; v < 9; ++v)
+        for (int m = 0; m < 4; ++m) {
+            const float4 f = src[(m >> 1) * (LPF_GP / 4) + (m & 1)];
+            win[4 * m] = (double)f.x; win[4 * m + 1] = (double)f.y; win[4 * m + 2] = (double)f.z; win[4 * m + 3] = (double)f.w;
+        }
 #pragma unroll
-        for (int u = 0; u < 9; ++u) sum += (double)(tile[(2 * oy + v) * LPF_IW + 2 * ox + u] * kLpf9[v * 9 + u]);
-    if (x0 + ox < sw && y0 + oy < sh) out[(size_t)(y0 + oy) * sw + x0 + ox] = (float)sum;
+        for (int u = 0; u < 9; ++u)
+#pragma unroll
+            for (int o = 0; o < LPF_OPT; ++o) sum[o] = __builtin_fma(win[2 * o + u], kLpf9D[v * 9 + u], sum[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < LPF_OPT; ++o)
+        if (x0 + ox0 + o < sw && y0 + oy < sh) out[(size_t)(y0 + oy) * sw + x0 + ox0 + o] = (float)sum[o];
 }
 
 // ssim_tools.h: g_gaussian_window_h == g_gaussian_window_v
-constexpr float kSsimWin[11] = { 0.001028f, 0.007599f, 0.036001f, 0.109361f, 0.213006f, 0.266012f, 0.213006f, 0.109361f,
-                                 0.036001f, 0.007599f, 0.001028f };
 constexpr int SS_TW = 64, SS_TH = 16, SS_IW = SS_TW + 10, SS_IH = SS_TH + 10, SS_IP = SS_IW + 2;   // staged 26 x 74 (pitch 76)
 constexpr int SS_SEG = 8;                                      // outputs per thread in the horizontal pass
 static_assert(SS_IH * (SS_TW / SS_SEG) <= 256 && SS_TW * (SS_TH / 4) == 256, "thread maps of ssim_stat_kernel");
 
-// 11-tap window sum of the reference: float products, double running sum, float result (iqa/convolve.c:113-143)
-template <int NOUT> __device__ __forceinline__ void ssim_taps(const float *win, float *out)
+// 11-tap window sum.  The reference (iqa/convolve.c:113-143) rounds every product img * k to float and adds the products
+// to a double running sum in tap order; the result is stored as float.  Here the running sum takes the products through
+// v_fma_f64: the product of two floats is exact in double (48 bits), so each term enters the sum WITHOUT the reference's
+// intermediate float rounding - one fp64 instruction per tap instead of v_mul_f32 + v_cvt_f64_f32 + v_add_f64 (fp64 issues
+// at half the fp32 rate on gfx950: 4 cycles instead of 10 per tap), and the samples are widened once per window, not once
+// per tap.  Same tap order, same double accumulator, same float result type; the window sums differ from the reference's
+// in the last float bit in a minority of samples (they are the more exact ones), SSIM / MS-SSIM by < 1e-7
+// (tests/test_gpu_parity.py::test_psnr_ssim_ms_ssim_match_oracle holds them to 1e-6 against the oracle, which keeps the
+// reference's arithmetic expression by expression).
+__device__ constexpr double kSsimWinD[11] = { (double)0.001028f, (double)0.007599f, (double)0.036001f, (double)0.109361f, (double)0.213006f,
+                                              (double)0.266012f, (double)0.213006f, (double)0.109361f, (double)0.036001f, (double)0.007599f,
+                                              (double)0.001028f };
+template <int NOUT> __device__ __forceinline__ void ssim_taps(const double *win, float *out)
 {
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) sum += (double)(win[o + k] * kSsimWin[k]);
+        for (int k = 0; k < 11; ++k) sum = __builtin_fma(win[o + k], kSsimWinD[k], sum);
         out[o] = (float)sum;
     }
 }
@@ -1288,12 +1344,18 @@ template <int NOUT> __device__ __forceinline__ void ssim_taps(const float *win, 
 // l / c / s per pixel in double, four sums per workgroup: sum(l*c*s), sum(l), sum(c), sum(s).
 // Horizontal pass: thread = (row, 8 outputs), the 18-sample windows of ref and cmp in registers, products formed
 // there; vertical pass: thread = (column, 4 outputs) with a 14-sample register window per quantity.
-__global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
+// CS_ONLY: the MS-SSIM levels 0..3, whose luminance term carries the exponent 0 (ms_ssim.c:62-64: pow(l, 0) = 1 whatever l
+// is): only sum(c) and sum(s) are formed, the l division is skipped and the l*c*s / l sums stay 0.
+template <bool CS_ONLY>
+__global__ __launch_bounds__(256, 4) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
                                                         double *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) float rt[SS_IH * SS_IP];
-    __shared__ __attribute__((aligned(16))) float ct[SS_IH * SS_IP];
-    __shared__ __attribute__((aligned(16))) float hc[5][SS_IH * SS_TW];
+    // one LDS area, used twice: the staged input tiles (rt, ct) until every thread of the horizontal pass holds its
+    // windows in registers, then the five horizontally filtered planes (hc) - 33 KB instead of 49: four workgroups per CU
+    __shared__ __attribute__((aligned(16))) float smem[5 * SS_IH * SS_TW];
+    static_assert(2 * SS_IH * SS_IP <= 5 * SS_IH * SS_TW, "the staged tiles fit the area of the filtered planes");
+    float *rt = smem, *ct = smem + SS_IH * SS_IP;
+    float (*hc)[SS_IH * SS_TW] = reinterpret_cast<float (*)[SS_IH * SS_TW]>(smem);
     __shared__ double red[16];
     const int tid = threadIdx.x;
     const int vw = w - 10, vh = h - 10;                              // valid output size
@@ -1323,9 +1385,10 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
         }
     }
     __syncthreads();
-    if (tid < SS_IH * (SS_TW / SS_SEG)) {
-        const int row = tid / (SS_TW / SS_SEG), seg = tid - row * (SS_TW / SS_SEG);
-        float a[SS_SEG + 10], b[SS_SEG + 10], t[SS_SEG + 10], o[SS_SEG];
+    const bool hthread = tid < SS_IH * (SS_TW / SS_SEG);
+    const int row = hthread ? tid / (SS_TW / SS_SEG) : 0, seg = hthread ? tid - row * (SS_TW / SS_SEG) : 0;
+    float a[SS_SEG + 10], b[SS_SEG + 10];
+    {
         const float2 *pa = reinterpret_cast<const float2 *>(rt + row * SS_IP + seg * SS_SEG);
         const float2 *pb = reinterpret_cast<const float2 *>(ct + row * SS_IP + seg * SS_SEG);
 #pragma unroll
@@ -1333,14 +1396,18 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
             const float2 u = pa[m], v = pb[m];
             a[2 * m] = u.x; a[2 * m + 1] = u.y; b[2 * m] = v.x; b[2 * m + 1] = v.y;
         }
+    }
+    __syncthreads();                                                  // rt / ct are dead: hc may overwrite them
+    if (hthread) {
+        float o[SS_SEG];
+        double t[SS_SEG + 10];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const float *src = q == 0 ? a : q == 1 ? b : t;
-            if (q >= 2) {
+            // the squares and the cross product are float products, as in ssim_tools.c:147-151
 #pragma unroll
-                for (int k = 0; k < SS_SEG + 10; ++k) t[k] = q == 2 ? a[k] * a[k] : q == 3 ? b[k] * b[k] : a[k] * b[k];
-            }
-            ssim_taps<SS_SEG>(src, o);
+            for (int k = 0; k < SS_SEG + 10; ++k)
+                t[k] = (double)(q == 0 ? a[k] : q == 1 ? b[k] : q == 2 ? a[k] * a[k] : q == 3 ? b[k] * b[k] : a[k] * b[k]);
+            ssim_taps<SS_SEG>(t, o);
             float4 *dst = reinterpret_cast<float4 *>(&hc[q][row * SS_TW + seg * SS_SEG]);
             dst[0] = make_float4(o[0], o[1], o[2], o[3]);
             dst[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -1356,9 +1423,9 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
         float m[5][4];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            float win[14];
+            double win[14];
 #pragma unroll
-            for (int k = 0; k < 14; ++k) win[k] = hc[q][(oy0 + k) * SS_TW + ox];
+            for (int k = 0; k < 14; ++k) win[k] = (double)hc[q][(oy0 + k) * SS_TW + ox];
             ssim_taps<4>(win, m[q]);
         }
 #pragma unroll
@@ -1372,11 +1439,14 @@ __global__ __launch_bounds__(256) void ssim_stat_kernel(const float *__restrict_
                 css = (float)((0.0 > css) ? 0.0 : css);
                 sb -= ref_mu * cmp_mu;
                 const double srsc = sqrt((double)(rss * css));
-                const double l = (2.0 * ref_mu * cmp_mu + C1) / (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
                 const double c = (2.0 * srsc + C2) / (double)(rss + css + C2);
                 const double s_ = (sb + C2 / 2.0) / (srsc + C2 / 2.0);
-                acc[0] += l * c * s_;
-                acc[1] += l; acc[2] += c; acc[3] += s_;
+                acc[2] += c; acc[3] += s_;
+                if (!CS_ONLY) {
+                    const double l = (2.0 * ref_mu * cmp_mu + C1) / (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
+                    acc[0] += l * c * s_;
+                    acc[1] += l;
+                }
             }
         }
     }
@@ -1627,10 +1697,11 @@ hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src
 }
 
 // ref, cmp: dense planes [nframes][h][w]; partial receives vk_ssim_tiles(w, h) * 4 doubles per frame
-hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, double *partial, hipStream_t s)
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, double *partial, hipStream_t s)
 {
     const dim3 g((w - 10 + SS_TW - 1) / SS_TW, (h - 10 + SS_TH - 1) / SS_TH, nframes);
-    ssim_stat_kernel<<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
+    if (cs_only) ssim_stat_kernel<true><<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
+    else ssim_stat_kernel<false><<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
     return hipGetLastError();
 }
 
