@@ -13,6 +13,8 @@
 #include <exception>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,6 +35,15 @@ private:
 };
 
 constexpr int kAtoms = VMAF_HIP_ATOMS;
+
+// VMAF_HIP_TRACE=1: wall-clock milestones of a compute_vmaf* call on stderr (where the fixed cost of a short run goes)
+void trace(const char *what)
+{
+    static const bool on = std::getenv("VMAF_HIP_TRACE") && std::atoi(std::getenv("VMAF_HIP_TRACE")) != 0;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[vmaf_hip %8.3f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
 
 struct EngineGuard {
     std::vector<vmaf_hip_engine *> engines;
@@ -172,6 +183,79 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, cons
     if (mf.any()) metrics.resize(total * VMAF_HIP_METRICS);
 }
 
+// Helper threads of one shard: the frames of a batch are fetched side by side (one positional read_frame call per frame,
+// frame i on thread i % N), because a single thread copies only ~8 GB/s out of the page cache - less than half of what
+// the PCIe link then moves.  One hand-off per batch, not per frame.
+class FrameFetchers {
+public:
+    explicit FrameFetchers(int helpers)
+    {
+        for (int i = 0; i < helpers; ++i) th_.emplace_back([this, i] { work(i + 1); });
+    }
+    ~FrameFetchers()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // calls fn(i) for i in [0, n) on the helpers and the calling thread; returns the first non-zero result (0 = all fine)
+    int run(int n, const std::function<int(int)> &fn)
+    {
+        const int parts = (int)th_.size() + 1;
+        if (th_.empty() || n <= 1) {
+            for (int i = 0; i < n; ++i) if (int rc = fn(i)) return rc;
+            return 0;
+        }
+        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; rc_ = 0; left_ = (int)th_.size(); ++gen_; }
+        cv_.notify_all();
+        int rc = 0;
+        for (int i = 0; i < n; i += parts) if (int r = fn(i)) { rc = r; break; }
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return left_ == 0; });
+        return rc ? rc : rc_;
+    }
+
+private:
+    void work(int me)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<int(int)> *fn;
+            int n;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_; n = n_;
+            }
+            const int parts = (int)th_.size() + 1;
+            int rc = 0;
+            for (int i = me; i < n; i += parts) if ((rc = (*fn)(i)) != 0) break;
+            std::lock_guard<std::mutex> l(m_);
+            if (rc && !rc_) rc_ = rc;
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<int(int)> *fn_ = nullptr;
+    int n_ = 0, rc_ = 0, left_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+
+// reader threads per shard: VMAF_HIP_READ_THREADS (default 8; vmafossexec's knob) split over the shards
+int fetch_threads(int shards)
+{
+    const char *env = std::getenv("VMAF_HIP_READ_THREADS");
+    int n = env ? std::atoi(env) : 8;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && n > hw) n = hw;
+    return std::max(1, n / std::max(1, shards));
+}
+
 int batch_frames(size_t plane)
 {
     // frames per batch: ~32 MB of luma per plane and batch (16 frames of raw 8-bit 1080p), see extract_atoms
@@ -184,13 +268,15 @@ int batch_frames(size_t plane)
 // reads and blurs ref frame start-1 itself (motion halo: ref only, no VIF/ADM), then walks its range in double-buffered
 // batches - the reads of batch k+1 overlap the copies and kernels of batch k.  Writes atoms[start..stop).
 void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar_order, const MetricFlags &mf, long start, long stop,
-                   double *atoms, double *metrics)
+                   int readers, double *atoms, double *metrics)
 {
     const size_t stride = (size_t)w * src.bps, plane = stride * h;
     const int batch = batch_frames(plane);
     EngineGuard guard;
     vmaf_hip_engine *e = nullptr;
+    trace("shard: engine create");
     if (vmaf_hip_engine_create(&e, device, w, h, batch)) throw VmafException(vmaf_hip_last_error());
+    trace("shard: engine created");
     guard.engines.push_back(e);
     static const bool fast = std::getenv("VMAF_HIP_FAST") && std::atoi(std::getenv("VMAF_HIP_FAST")) != 0;
     if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1)) throw VmafException(vmaf_hip_last_error());
@@ -204,6 +290,8 @@ void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar
             guard.pinned.push_back(*p);
         }
     }
+    trace("shard: page-locked buffers ready");
+    FrameFetchers fetch(readers - 1);
     auto read = [&](char *r, char *d, long frame) {
         const int ret = src.read_raw_at(r, d, (int)stride, frame, src.user);
         if (ret) throw VmafException("read_frame failed at frame " + std::to_string(frame) + ".");
@@ -227,14 +315,18 @@ void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar
     for (long at = start; at < stop; at += batch) {
         const int n = (int)std::min<long>(batch, stop - at);
         if (inflight == 2) collect();                              // frees buffer `fill`
-        for (int i = 0; i < n; ++i) read(ref[fill] + plane * i, dis[fill] + plane * i, at + i);
+        char *rb = ref[fill], *db = dis[fill];
+        const int bad = fetch.run(n, [&](int i) { return src.read_raw_at(rb + plane * i, db + plane * i, (int)stride, at + i, src.user) ? i + 1 : 0; });
+        if (bad) throw VmafException("read_frame failed at frame " + std::to_string(at + bad - 1) + ".");
         if (vmaf_hip_extract_host_raw_async(e, ref[fill], dis[fill], src.bps, stride, plane, n, at > 0 ? 1 : 0, out[fill].data()))
             throw VmafException(vmaf_hip_last_error());
         pend[fill] = { at, n };
         ++inflight;
         fill ^= 1;
     }
+    trace("shard: all batches enqueued");
     while (inflight) collect();
+    trace("shard: done");
 }
 
 // Frame-range sharding of ONE video over the devices of VMAF_HIP_DEVICES: device g scores frames [g*F/G, (g+1)*F/G) on its
@@ -256,7 +348,7 @@ void extract_atoms_sharded(const FrameSource &src, int w, int h, bool scalar_ord
     for (int g = 0; g < G; ++g) {
         const long start = F * g / G, stop = F * (g + 1) / G;
         th.emplace_back([&, g, start, stop] {
-            try { extract_shard(src, devices[g], w, h, scalar_order, mf, start, stop, atoms.data(), mf.any() ? metrics.data() : nullptr); }
+            try { extract_shard(src, devices[g], w, h, scalar_order, mf, start, stop, fetch_threads(G), atoms.data(), mf.any() ? metrics.data() : nullptr); }
             catch (const std::exception &ex) { errors[g] = ex.what(); if (errors[g].empty()) errors[g] = "unknown error"; }
         });
     }
@@ -420,6 +512,7 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
                 const char *model_path, const char *log_path, const char *log_fmt, bool disable_clip, bool disable_avx,
                 bool enable_transform, bool do_psnr, bool do_ssim, bool do_ms_ssim, const char *pool_method)
 {
+    trace("run_vmaf: start");
     std::printf("Start calculating VMAF score...\n");             // vmaf.cpp:638
     if (!model_path) throw VmafException("Error loading model (.pkl): null path");
     if (!(src.read_raw_at ? (void *)src.read_raw_at : src.bps ? (void *)src.read_raw : (void *)src.read_frame)) throw VmafException("read_frame callback is null");
@@ -428,6 +521,7 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
     try { model = vmaf_amd::load_vmaf_model(model_path); }
     catch (const std::runtime_error &e) { throw VmafException(e.what()); }
 
+    trace("run_vmaf: model loaded");
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> atoms;
     MetricFlags mf;
@@ -441,7 +535,9 @@ double run_vmaf(const char *fmt, int width, int height, const FrameSource &src,
     if (F == 0) throw VmafException("no frames delivered by read_frame");
     std::vector<double> vmaf;
     std::map<std::string, std::vector<double>> result;            // std::map: keys in alphabetical order, vmaf.h:126-134
+    trace("run_vmaf: atoms extracted");
     fuse(model, atoms, F, disable_clip, enable_transform, parse_devices()[0], vmaf, result);
+    trace("run_vmaf: fused");
     result["vmaf"] = vmaf;
     const char *mnames[3] = { "psnr", "ssim", "ms_ssim" };            // vmaf.cpp:595-597
     const bool mon[3] = { do_psnr, do_ssim, do_ms_ssim };

@@ -2,13 +2,10 @@
 // reference CLI (wrapper/src/main.cpp:49-232), with its own file-backed read_frame callback
 // (behaviour of feature/src/common/frame.c:26-129 + file_io.c:86-172).
 #include <algorithm>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
-#include <memory>
-#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,81 +17,6 @@
 
 namespace {
 
-// A few reader threads for regular files: one luma plane is copied from the page cache into the library's page-locked
-// buffer as several pread() chunks side by side (a single copying thread moves ~8 GB/s, which would cap the CLI at
-// ~3 000 1080p frames/s).  Pipes and FIFOs keep the sequential fread path below.
-class ReadPool {
-public:
-    struct Job { int fd; char *dst; size_t n; off_t off; ssize_t got; };
-    explicit ReadPool(int nthreads)
-    {
-        for (int i = 0; i < nthreads; ++i) th_.emplace_back([this] { work(); });
-    }
-    ~ReadPool()
-    {
-        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    // runs every job (the calling thread helps), returns when all are done
-    void run(std::vector<Job> &jobs)
-    {
-        { std::lock_guard<std::mutex> l(m_); jobs_ = &jobs; next_ = 0; left_ = jobs.size(); }
-        cv_.notify_all();
-        for (;;) {
-            Job *j = take();
-            if (!j) break;
-            do_read(*j);
-            finish();
-        }
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return left_ == 0; });
-        jobs_ = nullptr;
-    }
-
-    static void do_read(Job &j)
-    {
-        j.got = 0;
-        while ((size_t)j.got < j.n) {                            // pread may return less than asked
-            const ssize_t r = ::pread(j.fd, j.dst + j.got, j.n - (size_t)j.got, j.off + j.got);
-            if (r < 0) { j.got = -1; return; }
-            if (r == 0) return;                                  // end of file
-            j.got += r;
-        }
-    }
-private:
-    Job *take()
-    {
-        std::lock_guard<std::mutex> l(m_);
-        return (jobs_ && next_ < jobs_->size()) ? &(*jobs_)[next_++] : nullptr;
-    }
-    void finish()
-    {
-        std::lock_guard<std::mutex> l(m_);
-        if (--left_ == 0) done_.notify_all();
-    }
-    void work()
-    {
-        for (;;) {
-            Job *j = nullptr;
-            {
-                std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [this] { return stop_ || (jobs_ && next_ < jobs_->size()); });
-                if (stop_) return;
-                j = &(*jobs_)[next_++];
-            }
-            do_read(*j);
-            finish();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    std::vector<Job> *jobs_ = nullptr;
-    size_t next_ = 0, left_ = 0;
-    bool stop_ = false;
-};
-
 struct YuvPair {
     FILE *ref = nullptr, *dis = nullptr;
     int width = 0, height = 0;
@@ -103,7 +25,6 @@ struct YuvPair {
     std::vector<unsigned char> row;
     // regular files (compute_vmaf_raw_seekable): frames are read by position, from several shard threads at once
     size_t luma_bytes = 0, frame_bytes = 0;
-    int threads_per_shard = 1;
 };
 
 // One luma plane -> fp32 in 8-bit units (10-bit: value / 4.0, file_io.c:159-163). 0 ok, 1 short read.
@@ -175,28 +96,25 @@ int read_frame_raw_cb(void *ref_luma, void *dis_luma, int stride_byte, void *use
     return ref_rc ? ref_rc : dis_rc;                             // frame.c:48-78: the ref read is checked first
 }
 
-// Positional form for regular files (compute_vmaf_raw_seekable): the luma planes of frame `index`, each as a few pread()
-// chunks side by side on the calling shard's own little pool of reader threads (made on first use, ended with the
-// shard's thread).  Called concurrently from one thread per shard; touches no shared state but the two descriptors.
+// Positional form for regular files (compute_vmaf_raw_seekable): the two luma planes of frame `index` by pread().  The
+// library calls it from several threads at once (shards, and the reader threads of a shard: VMAF_HIP_READ_THREADS);
+// it touches no shared state but the two descriptors.
 int read_frame_raw_at_cb(void *ref_luma, void *dis_luma, int stride_byte, long index, void *user)
 {
     const YuvPair &s = *(const YuvPair *)user;
     const size_t bytes = (size_t)stride_byte * s.height;
     if (bytes != s.luma_bytes) return 1;
-    thread_local std::unique_ptr<ReadPool> pool;
-    thread_local std::vector<ReadPool::Job> jobs;
-    if (!pool && s.threads_per_shard > 1) pool.reset(new ReadPool(s.threads_per_shard - 1));     // the shard's thread reads too
-    const int chunks = std::max(1, s.threads_per_shard / 2);
-    const size_t per = (bytes + chunks - 1) / chunks;
     const off_t at = (off_t)index * (off_t)s.frame_bytes;
-    jobs.clear();
-    for (int f = 0; f < 2; ++f)
-        for (size_t o = 0; o < bytes; o += per)
-            jobs.push_back({ fileno(f ? s.dis : s.ref), (char *)(f ? dis_luma : ref_luma) + o, std::min(per, bytes - o), at + (off_t)o, 0 });
-    if (pool) pool->run(jobs);
-    else for (auto &j : jobs) ReadPool::do_read(j);
-    for (auto &j : jobs)
-        if (j.got < 0 || (size_t)j.got != j.n) return 1;           // the frame count was taken from the file sizes: a short read is a failure
+    for (int f = 0; f < 2; ++f) {
+        char *dst = (char *)(f ? dis_luma : ref_luma);
+        const int fd = fileno(f ? s.dis : s.ref);
+        size_t got = 0;
+        while (got < bytes) {                                    // pread may return less than asked
+            const ssize_t r = ::pread(fd, dst + got, bytes - got, at + (off_t)got);
+            if (r <= 0) return 1;                                // the frame count was taken from the file sizes: a short read is a failure
+            got += (size_t)r;
+        }
+    }
     return 0;
 }
 
@@ -273,14 +191,11 @@ int main(int argc, char *argv[])
     bool seekable = false;
     long nframes = 0;
     if (!ret) {
-        // regular files are read by position: reader threads (VMAF_HIP_READ_THREADS, default 8; 0 or 1 = the shard's own
-        // thread only), and frame-range shards over the devices of VMAF_HIP_DEVICES.  Pipes and FIFOs keep the
+        // regular files are read by position: the library fetches the frames of a batch on several threads
+        // (VMAF_HIP_READ_THREADS, default 8; 0 or 1 = the shard's own thread only) and splits the video into frame-range
+        // shards over the devices of VMAF_HIP_DEVICES.  Pipes and FIFOs keep the
         // sequential path.  VMAF_HIP_SEEKABLE=0 forces the sequential path for files too.
         struct stat sr, sd;
-        const char *env = std::getenv("VMAF_HIP_READ_THREADS");
-        int nthreads = env ? std::atoi(env) : 8;
-        const int hw = (int)std::thread::hardware_concurrency();
-        if (hw > 0 && nthreads > hw) nthreads = hw;
         const char *sk = std::getenv("VMAF_HIP_SEEKABLE");
         const bool allow = !(sk && *sk == '0');
         if (allow && fstat(fileno(s.ref), &sr) == 0 && fstat(fileno(s.dis), &sd) == 0 && S_ISREG(sr.st_mode) && S_ISREG(sd.st_mode)) {
@@ -288,9 +203,6 @@ int main(int argc, char *argv[])
             s.luma_bytes = n * bps;
             s.frame_bytes = (n + s.chroma_samples) * bps;
             nframes = std::min(frames_in(sr.st_size, s.luma_bytes, s.frame_bytes), frames_in(sd.st_size, s.luma_bytes, s.frame_bytes));
-            int shards = 1;
-            if (const char *dv = std::getenv("VMAF_HIP_DEVICES")) shards = 1 + (int)std::count(dv, dv + std::strlen(dv), ',');
-            s.threads_per_shard = std::max(1, nthreads / std::max(1, shards));
             seekable = nframes > 0;                              // an empty pair takes the sequential path and its error message
         }
     }

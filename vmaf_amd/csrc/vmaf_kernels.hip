@@ -802,9 +802,14 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
     const int tid = threadIdx.x;
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     const int ntx = (bw + ADM_TW - 1) / ADM_TW;
-    // XCD-aware order with the tile ROWS dealt round-robin over the eight runs (run k = rows k, k+8, ..): the rows above and
-    // below the centre window are cheap (see in_window below), and contiguous bands would leave the first and last XCD idle
+    // XCD-aware order: the workgroups one XCD receives (round-robin dispatch: blocks b, b+8, ..) cover a contiguous run of
+    // tiles = a band of tile rows, so that the halo rows of vertically neighbouring tiles meet in that XCD's L2.  The rows
+    // above and below the centre window are cheap (see in_window below), which would leave the XCDs with the outer bands
+    // idle at the end of the launch - so the band an XCD takes rotates from frame to frame (VMAF_ADM_ROWS_RR: the older
+    // scheme, tile rows dealt round-robin over the XCDs inside every frame: balanced too, but vertical neighbours never
+    // share an L2 and the input is read 1.21x)
     int tile_id;
+#ifdef VMAF_ADM_ROWS_RR
     {
         const int nty = (bh + ADM_TH - 1) / ADM_TH;
         const int i = xcd_tile_index(), p = i / ntx;           // p-th row of the permuted order
@@ -817,6 +822,32 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
         }
         tile_id = row * ntx + (i - p * ntx);
     }
+#else
+    {
+        const int b = blockIdx.x, nt = gridDim.x;
+        const int xcd = (b + blockIdx.z) & 7;                  // the run this workgroup's XCD takes in this frame
+        const int q = nt >> 3, r = nt & 7;
+        // runs differ in length by at most one tile; a rotated XCD may hold one block more or less than its run: the
+        // index is taken modulo the run layout, which stays a bijection because (b >> 3) enumerates every run's blocks
+        const int run_len = q + (xcd < r ? 1 : 0), run_start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int j = b >> 3;
+        tile_id = j < run_len ? run_start + j : -1;
+        if (tile_id < 0) {
+            // the block of a longer physical slot that has no tile in the (shorter) rotated run: it takes the tile the
+            // opposite rotation leaves over - the last tile of the run that is longer than its physical slot
+            const int src = b & 7;                             // physical slot: has q + 1 blocks, so src < r
+            // runs with q + 1 tiles whose rotated slot has only q blocks: rotated run index x with x < r and ((x - z) & 7) >= r
+            int k = 0, want = 0;
+            for (int s2 = 0; s2 < src; ++s2) want += (((s2 + blockIdx.z) & 7) >= r) ? 1 : 0;   // how many such blocks precede this one
+            for (int x = 0; x < 8; ++x) {
+                if (x < r && ((x - (int)blockIdx.z) & 7) >= r) {
+                    if (k == want) { tile_id = x * (q + 1) + q; }
+                    ++k;
+                }
+            }
+        }
+    }
+#endif
     const int cx0 = (tile_id % ntx) * ADM_TW, cy0 = (tile_id / ntx) * ADM_TH;   // first interior coefficient
     const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
