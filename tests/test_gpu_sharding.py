@@ -130,3 +130,28 @@ def test_bench_multi_rank_control_flow_rehearsal():
     assert doc["n_gpus"] == 2 and doc["value"] > 0 and doc["scaling"] == "weak"
     assert doc["config"]["frames_total"] == 2 * 3 * doc["config"]["frames_per_step_per_gpu"]
     assert 0.0 < doc["mean_vmaf"] <= 100.0
+
+
+def test_seekable_entry_from_a_non_cli_caller(tmp_path, monkeypatch):
+    """compute_vmaf_raw_seekable through ctypes with a positional callback that owns the frames in memory (what a decoder
+    with random access binds): same log as the pull-based compute_vmaf on the same frames, for 1 and 3 shards x 1 and 4
+    reader threads; every frame is asked for exactly once plus one halo frame per later shard; a failing read ends the
+    call with the frame named instead of a hang or a partial score."""
+    from vmaf_amd import binding
+    r, d = synth.make_clip(320, 180, 13, bits=10, seed=31, cuts=(5,))
+    log0 = str(tmp_path / "pull.xml")
+    want = binding.compute_vmaf_from_arrays(synth.to_luma_f32(r, 10), synth.to_luma_f32(d, 10), fmt="yuv420p10le", log_path=log0, phone_model=True)
+    base = re.sub(r'execFps="[^"]*"', "", open(log0).read())
+    for devs, threads in (("0", "1"), ("0", "4"), ("0,0,0", "1"), ("0,0,0", "12")):
+        monkeypatch.setenv("VMAF_HIP_DEVICES", devs)
+        monkeypatch.setenv("VMAF_HIP_READ_THREADS", threads)
+        monkeypatch.setenv("VMAF_HIP_BATCH", "4")
+        log = str(tmp_path / "seek.xml")
+        got, seen = binding.compute_vmaf_seekable_from_arrays(r, d, fmt="yuv420p10le", log_path=log, phone_model=True)
+        assert got == want
+        assert re.sub(r'execFps="[^"]*"', "", open(log).read()) == base
+        shards = devs.count(",") + 1
+        halos = sorted(13 * g // shards - 1 for g in range(1, shards))
+        assert seen == sorted(list(range(13)) + halos)
+        with pytest.raises(vmaf_amd.VmafHipError, match="read_frame failed at frame 9"):
+            binding.compute_vmaf_seekable_from_arrays(r, d, fmt="yuv420p10le", fail_at=9)

@@ -28,6 +28,7 @@ class VmafHipError(RuntimeError):
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
 READ_FRAME = C.CFUNCTYPE(C.c_int, _fp, _fp, _fp, C.c_int, C.c_void_p)
+READ_FRAME_RAW_AT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_void_p)
 _lib = None
 
 
@@ -79,6 +80,8 @@ def load_library():
     L.vmaf_hip_last_kernel_ms.restype = C.c_double
     L.compute_vmaf_noexcept.argtypes = [_dp, C.c_char_p, i, i, READ_FRAME, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                         i, i, i, i, i, i, i, C.c_char_p, C.c_char_p, i]
+    L.compute_vmaf_raw_seekable_noexcept.argtypes = [_dp, C.c_char_p, i, i, C.c_long, READ_FRAME_RAW_AT, vp, C.c_char_p, C.c_char_p, C.c_char_p,
+                                                     i, i, i, i, i, i, i, C.c_char_p, C.c_char_p, i]
     L.vmaf_amd_predict_from_atoms.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, i, C.c_char_p, i]
     L.vmaf_amd_model_feature_names.argtypes = [C.c_char_p, C.POINTER(i), C.c_char_p, i, C.c_char_p, i]
     _lib = L
@@ -398,3 +401,34 @@ def compute_vmaf_from_arrays(ref, dis, fmt="yuv420p", model_path=DEFAULT_MODEL, 
     if rc:
         raise VmafHipError(err.value.decode(errors="replace"))
     return score.value
+
+
+def compute_vmaf_seekable_from_arrays(ref, dis, fmt="yuv420p", model_path=DEFAULT_MODEL, log_path=None, log_fmt=None,
+                                      disable_clip=False, enable_transform=False, phone_model=False, pool_method=None,
+                                      do_psnr=False, do_ssim=False, do_ms_ssim=False, disable_avx=False, fail_at=None):
+    """Drive compute_vmaf_raw_seekable() from raw luma arrays [F,h,w] (uint8, or uint16 for the *10le formats): the
+    positional callback is called from the library's shard and reader threads (VMAF_HIP_DEVICES, VMAF_HIP_READ_THREADS).
+    fail_at = a frame index whose read reports failure (tests)."""
+    L = load_library()
+    ref, dis = np.ascontiguousarray(ref), np.ascontiguousarray(dis)
+    F, h, w = ref.shape
+    bps = ref.dtype.itemsize
+    seen = []
+
+    def cb(rp, dp_, stride, index, user):
+        seen.append(index)
+        if index < 0 or index >= F or stride != w * bps or index == fail_at:
+            return 1
+        C.memmove(rp, ref[index].ctypes.data, w * h * bps)
+        C.memmove(dp_, dis[index].ctypes.data, w * h * bps)
+        return 0
+
+    score = C.c_double()
+    err = C.create_string_buffer(1024)
+    enc = lambda s: s.encode() if s is not None else None  # noqa: E731
+    rc = L.compute_vmaf_raw_seekable_noexcept(C.byref(score), fmt.encode(), w, h, F, READ_FRAME_RAW_AT(cb), None, model_path.encode(),
+                                              enc(log_path), enc(log_fmt), int(disable_clip), int(disable_avx), int(enable_transform),
+                                              int(phone_model), int(do_psnr), int(do_ssim), int(do_ms_ssim), enc(pool_method), err, 1024)
+    if rc:
+        raise VmafHipError(err.value.decode(errors="replace"))
+    return score.value, sorted(seen)
