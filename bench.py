@@ -114,6 +114,7 @@ def end_to_end(r8, d8, order, device):
     reference's read_frame contract, 8 B/px).  (2) the CLI: vmaf_amd/vmafossexec on a 600-frame yuv420p pair in /dev/shm,
     the whole process (start-up, engine creation, file reading, scoring, fusion)."""
     import re
+    import shutil
     import subprocess
     import tempfile
     from vmaf_amd.binding import PinnedArray
@@ -152,7 +153,9 @@ def end_to_end(r8, d8, order, device):
             pr.close()
             pd.close()
     exe = os.path.join(ROOT, "vmaf_amd", "vmafossexec")
-    if os.path.exists(exe) and os.path.isdir("/dev/shm"):
+    frame_bytes = W * H * (2 if BITS == 10 else 1) * 3 // 2
+    shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * 1200 * frame_bytes + (1 << 30)
+    if os.path.exists(exe) and shm_ok:
         fmt = "yuv420p10le" if BITS == 10 else "yuv420p"
         with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
             rp, dp = os.path.join(tmp, "ref.yuv"), os.path.join(tmp, "dis.yuv")
@@ -371,10 +374,17 @@ def main():
             line["fast_mode"] = fast
         if args.order != "avx":
             line["config"]["conv_order"] = args.order
+        # the two side figures must never cost the headline line: a full /dev/shm or a missing oracle build is reported, not raised
         if world == 1 and not args.no_end_to_end and not args.metrics:
-            line["end_to_end"] = end_to_end(r8, d8, args.order, local_rank)
+            try:
+                line["end_to_end"] = end_to_end(r8, d8, args.order, local_rank)
+            except Exception as exc:                                  # noqa: BLE001
+                line["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ref, dis)
+            try:
+                line["cpu_baseline"] = cpu_baseline(ref, dis)
+            except Exception as exc:                                  # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:
