@@ -62,7 +62,9 @@ def test_atoms_match_oracle(w, h, frames, order):
 FUZZ_CASES = [(47, 33, 8, "avx", 1), (48, 32, 8, "scalar", 2), (49, 65, 10, "avx", 2), (60, 61, 8, "avx", 3), (61, 60, 8, "scalar", 1),
               (95, 97, 8, "avx", 2), (96, 96, 10, "scalar", 2), (97, 95, 8, "avx", 1), (121, 57, 8, "avx", 2), (122, 56, 8, "scalar", 2),
               (123, 57, 10, "avx", 1), (244, 56, 8, "avx", 2), (245, 113, 8, "scalar", 1), (32, 32, 8, "avx", 3), (257, 131, 10, "avx", 2),
-              (419, 299, 8, "scalar", 2)]
+              (419, 299, 8, "scalar", 2),
+              # wide tiles whose last tile of a row is narrow: 8, 16 and 248 columns, and 2 tiles + 1 strip
+              (248, 40, 8, "avx", 2), (256, 33, 10, "avx", 2), (488, 57, 8, "avx", 1), (488, 57, 8, "scalar", 1), (304, 33, 8, "avx", 2)]
 
 
 @pytest.mark.parametrize("w,h,bits,order,frames", FUZZ_CASES)
@@ -98,13 +100,14 @@ EXACT_RTOL = 2e-12
 
 
 @pytest.mark.parametrize("order", ["avx", "scalar"])
-@pytest.mark.parametrize("w,h", [(240, 321), (480, 321), (481, 321), (96, 64), (250, 37)])
+@pytest.mark.parametrize("w,h", [(240, 321), (480, 321), (481, 321), (96, 64), (250, 37), (248, 321), (472, 321)])
 def test_every_vif_pixel_is_pinned_through_the_fp64_sums(golden_dir, order, w, h):
     """The VIF kernels add their per-pixel fp32 num / den values in fp64; the oracle can add the same values in extended
     precision (oracle.vif_exact_sums).  If every pixel's value is bit-identical, the two sums agree to ~1e-14; a single
     region in the wrong summation order (a few hundred pixels, each off by one fp32 rounding) moves them by >= 1e-11.
     Crops of tests/golden/images/100007 (the pair on which the reference's own two orders end up 3.7e-3 VMAF apart):
-    widths 240 / 480 run the workgroup-wide tiles (edge strips, top / bottom rows), 481 / 96 / 250 the wave-private tiles
+    widths 240 / 480 run the workgroup-wide tiles (edge strips, top / bottom rows), 248 / 472 the same with a narrow last
+    tile, 481 / 96 / 250 the wave-private tiles
     with their border frame.  The opposite order must miss the bound, or the test would prove nothing."""
     ref = np.fromfile(os.path.join(golden_dir, "images", "100007.yuv"), np.uint8)[:481 * 321].reshape(321, 481)[:h, :w].astype(np.float32)
     dis = np.fromfile(os.path.join(golden_dir, "images", "100007_noisy.yuv"), np.uint8)[:481 * 321].reshape(321, 481)[:h, :w].astype(np.float32)

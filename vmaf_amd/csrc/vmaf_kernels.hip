@@ -539,8 +539,8 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_
 }
 
 // ---------------------------------------------------------------- VIF, workgroup-wide tiles
-// Same arithmetic as vif_wave_tile, other work distribution, for planes whose width is a multiple of 240 (every level of
-// the 1080p and 4K pyramids).  A wave-private 48-column tile spends a third of its vertical pass on halo columns
+// Same arithmetic as vif_wave_tile, other work distribution, for planes at least 240 wide whose width is a multiple of 8
+// (every level of the 1080p and 4K pyramids tiles exactly; elsewhere the last tile of a row is narrower).  A wave-private 48-column tile spends a third of its vertical pass on halo columns
 // (64 filtered columns per 48 outputs at 17 taps); here the four waves of a workgroup stand side by side on 256 columns
 // and share the vertical results through LDS: 256 filtered columns per 240 outputs.
 //   vertical pass     thread = one of the 256 columns x0-R .. ; its 8+2R input rows from global memory, {r, d, r^2, d^2, rd}
@@ -586,18 +586,20 @@ template <int FW, bool OFFSET, int ORDER>
 __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_kernel(VIF_KERNEL_PARAMS)
 {
     using G = VifWgGeom<FW>;
-    constexpr int R = G::R, P = VWG_P, DFW = G::DFW, RD = G::RD, DVW = G::DVW, DP = G::DP;
+    constexpr int R = G::R, P = VWG_P, DFW = G::DFW, RD = G::RD, DP = G::DP;
     constexpr int NW = VWG_TH + 2 * R;
     __shared__ __attribute__((aligned(16))) float smem[G::V_FLOATS + G::D_FLOATS];
     __shared__ double red[2 * (VIF_THREADS / 64)];
     float *vout = smem, *dv_s = smem + G::V_FLOATS;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntx = w / VWG_TW;
+    const int ntx = (w + VWG_TW - 1) / VWG_TW;
     const int ntiles = gridDim.x;
     const int tile_id = xcd_tile_index();
     const int tx = tile_id % ntx;
     const int x0 = tx * VWG_TW, y0 = (tile_id / ntx) * VWG_TH;
+    // the last tile of a row may be narrower (w % 8 == 0: a whole number of strips); waves and threads beyond it idle
+    const int tw = min(VWG_TW, w - x0), nstrips = tw / VWG_HS;
     const float *fr = ref + (size_t)blockIdx.z * frame_stride;
     const float *fd = dis + (size_t)blockIdx.z * frame_stride;
     double acc[2] = { 0.0, 0.0 };
@@ -605,9 +607,9 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
     // ---- vertical pass: thread = column x0 - R + tid
     float vo[5][VWG_TH];
     const int vc = tid;
-    const bool vlane = vc < VWG_TW + 2 * R;                    // FW < 17 needs fewer than 256 columns
+    const bool vlane = vc < tw + 2 * R;                        // FW < 17 or a narrow last tile: fewer than 256 columns
     const int gxc = mirror_idx(x0 - R + vc, w);
-    {
+    if (wv * 64 < tw + 2 * R) {                                // wave-uniform: a wave without columns skips the pass
         float rv[NW], dv[NW], t[NW];
         const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
         const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
         if (DFW > 0) {
             // decimation, vertical pass at the even rows (y0 is even): output row y0 + 2i is window element R + 2i.
             // w % 8 == 0: every column is in the vector order of the vertical pass (convolution_avx.c:806-815)
-            const bool dcol = vc >= R - RD && vc < R - RD + DVW;
+            const bool dcol = vc >= R - RD && vc < R - RD + tw + 2 * RD;
 #pragma unroll
             for (int i = 0; i < VWG_TH / 2; ++i) {
                 const bool avx = ORDER == ORDER_AVX && avx_row_ok(y0 + 2 * i, h, RD);
@@ -661,13 +663,13 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
     // ---- horizontal pass
     int row, strip;
     vwg_item(tid, row, strip);
-    const bool hlane = tid < VWG_TH * VWG_STRIPS;
+    const bool hlane = tid < VWG_TH * VWG_STRIPS && strip < nstrips;
     // edge strips (ORDER_AVX only): columns [0, 8) of the plane and [w - 8, w); one wave each, lane = (row, column)
     const int hend = avx_hcol_end(w, R);
     const bool edge_l = ORDER == ORDER_AVX && tx == 0, edge_r = ORDER == ORDER_AVX && tx == ntx - 1;
     const bool edge_wave = (edge_l && wv == 0) || (edge_r && wv == 1);          // wave-uniform
     const int lane = tid & 63;
-    const int erow = lane & 7, ecol = (wv == 0 ? 0 : VWG_TW - VWG_HS) + (lane >> 3);   // column inside the tile
+    const int erow = lane & 7, ecol = (wv == 0 ? 0 : tw - VWG_HS) + (lane >> 3);       // column inside the tile
     float ho[5][VWG_HS], he[5];
 #pragma unroll
     for (int round = 0; round < (5 + G::VQ - 1) / G::VQ; ++round) {
@@ -687,9 +689,9 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
             // decimation, horizontal pass at the even columns (x0 is even) -> next scale's planes; thread = (plane, output
             // row, strip of 4 outputs): a row of a tile leaves as 120 consecutive floats, one 16-byte store per thread
             constexpr int DSH = G::DSH, DNW = 2 * (DSH - 1) + (DFW ? DFW : 1);
-            if (tid < 2 * (VWG_TH / 2) * (VWG_TW / 2 / DSH)) {
-                const int ds = tid % (VWG_TW / 2 / DSH), dr = (tid / (VWG_TW / 2 / DSH)) & 3, pl = tid / (4 * (VWG_TW / 2 / DSH));
-                const int ox0 = ds * DSH;
+            const int ds = tid % (VWG_TW / 2 / DSH), dr = (tid / (VWG_TW / 2 / DSH)) & 3, pl = tid / (4 * (VWG_TW / 2 / DSH));
+            const int ox0 = ds * DSH;
+            if (tid < 2 * (VWG_TH / 2) * (VWG_TW / 2 / DSH) && 2 * ox0 < tw) {
                 const int oh = h / 2, dend = avx_hcol_end(w, RD);
                 const float *src = dv_s + (pl * (VWG_TH / 2) + dr) * DP + 2 * ox0;
                 float dw[DNW], val[DSH];
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
     }
     if (hlane) {
         const int gy = y0 + row;
-        const bool in_edge = (edge_l && strip == 0) || (edge_r && strip == VWG_STRIPS - 1);
+        const bool in_edge = (edge_l && strip == 0) || (edge_r && strip == nstrips - 1);
         if (gy < h && !in_edge) {
 #pragma unroll
             for (int o = 0; o < VWG_HS; ++o) {
@@ -1597,17 +1599,17 @@ inline dim3 grid_flat(int w, int h, int tw, int th, int nframes) { return dim3((
 // ---------------------------------------------------------------- launchers
 extern "C" {
 
-// Planes whose width is a multiple of 240 (and of 8: no scalar-order columns but the two edge strips) take the
-// workgroup-wide tiles of vif_stat_wg_kernel; every other size the wave-private 48x32 tiles.  VMAF_HIP_VIF_WG=0 turns
-// the wide tiles off (A/B measurements).
+// Planes at least 240 wide whose width is a multiple of 8 (no scalar-order columns but the two edge strips; the last tile
+// of a row may be narrower) take the workgroup-wide tiles of vif_stat_wg_kernel; every other size the wave-private 48x32
+// tiles.  VMAF_HIP_VIF_WG=0 turns the wide tiles off (A/B measurements).
 static bool vif_use_wg(int w, int h)
 {
     static const int env = getenv("VMAF_HIP_VIF_WG") ? atoi(getenv("VMAF_HIP_VIF_WG")) : 1;
-    return env != 0 && w >= VWG_TW && w % VWG_TW == 0 && h >= 17;
+    return env != 0 && w >= VWG_TW && w % 8 == 0 && h >= 17;
 }
 int vk_vif_tiles(int w, int h)
 {
-    if (vif_use_wg(w, h)) return (w / VWG_TW) * ((h + VWG_TH - 1) / VWG_TH);
+    if (vif_use_wg(w, h)) return ((w + VWG_TW - 1) / VWG_TW) * ((h + VWG_TH - 1) / VWG_TH);
     return ((w + VIF_TW - 1) / VIF_TW) * ((h + VIF_TH - 1) / VIF_TH);
 }
 int vk_adm_tiles(int w, int h)
