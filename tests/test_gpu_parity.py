@@ -336,11 +336,14 @@ def test_raw_luma_device_pointers_and_errors():
         assert "bytes_per_sample" in vmaf_amd.binding._err(e.L)
 
 
-@pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 1280, 720), (10, 577, 325), (8, 200, 180), (8, 1920, 1080)])
+@pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 1280, 720), (10, 577, 325), (8, 200, 180), (8, 1920, 1080),
+                                      (8, 1030, 520), (10, 1301, 1281), (8, 2050, 2062)])
 def test_psnr_ssim_ms_ssim_match_oracle(bits, w, h):
     """the optional per-frame metrics of combo.c:168-230 (psnr.c, ssim.c, ms_ssim.c) on the GPU against
     the C restatement (itself bit-exact against the compiled reference, tests/test_oracle_vs_ref.py).  Covers SSIM
-    decimation factors 1, 3 and 4, odd sizes and the 10-bit PSNR peak.  Reference test tolerance: places=4."""
+    decimation factors 1, 2, 3, 4, 5 and 8, odd sizes and the 10-bit PSNR peak.  Reference test tolerance: places=4.
+    With all three metrics on, the PSNR sums come from the MS-SSIM level-0 launch (its last tiles take the 10 border
+    columns / rows); the PSNR-only engine below takes psnr_kernel and must give the same bits to 1e-9."""
     frames = 2 if w >= 1280 else 3
     r, d = synth.make_clip(w, h, frames, bits=bits, seed=50 + w)
     ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
@@ -352,6 +355,9 @@ def test_psnr_ssim_ms_ssim_match_oracle(bits, w, h):
         assert np.array_equal(e.metrics, got)          # raw ingest: same planes, same metrics
     with vmaf_amd.Engine(w, h, max_batch=2) as e:      # the metrics do not disturb the VMAF atoms
         assert np.array_equal(e.extract(ref, dis), atoms)
+        e.enable_metrics(psnr=True, ssim=False, ms_ssim=False, ten_bit=bits == 10)
+        e.extract(ref, dis)
+        assert np.allclose(e.metrics[:, 0], got[:, 0], rtol=0, atol=1e-9)
     assert got.shape == (frames, vmaf_amd.binding.N_METRICS)
     for f in range(frames):
         want = (oracle.psnr(ref[f], dis[f], bits), oracle.ssim(ref[f], dis[f])[0], oracle.ms_ssim(ref[f], dis[f])[0])

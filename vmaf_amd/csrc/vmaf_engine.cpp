@@ -288,27 +288,30 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     }
 
     // ---- optional metrics on their own stream (combo.c:168-230: before the -128 offset, i.e. on the planes as given)
+    static const bool psnr_fuse_env = !getenv("VMAF_HIP_PSNR_FUSED") || atoi(getenv("VMAF_HIP_PSNR_FUSED")) != 0;   // 0: A/B measurements
+    const bool psnr_fused = psnr_fuse_env && e->m_psnr && e->m_ms;
     if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) {
         hipStream_t q = e->s_iqa;
         HIP_TRY(hipStreamWaitEvent(q, e->ev_in, 0));
-        if (e->m_psnr) HIP_TRY(vk_launch_psnr(d_ref, d_dis, fs, rs, e->w, e->h, nframes, e->partials + e->part_off_psnr, q));
+        // with MS-SSIM on, its full-resolution launch forms the PSNR noise sums from the samples it stages (one read less)
+        if (e->m_psnr && !psnr_fused) HIP_TRY(vk_launch_psnr(d_ref, d_dis, fs, rs, e->w, e->h, nframes, e->partials + e->part_off_psnr, q));
         if (e->m_ansnr) HIP_TRY(vk_launch_ansnr(d_ref, d_dis, fs, rs, e->w, e->h, nframes, e->partials + e->part_off_ansnr, q));
         if (e->m_ssim) {
             const float *sr = d_ref, *sd = d_dis;
             if (e->ssim_f > 1) {
-                HIP_TRY(vk_launch_box_decimate(d_ref, fs, rs, e->w, e->h, e->ssim_f, e->ssim_ref, e->ssim_w, e->ssim_h, nframes, q));
-                HIP_TRY(vk_launch_box_decimate(d_dis, fs, rs, e->w, e->h, e->ssim_f, e->ssim_dis, e->ssim_w, e->ssim_h, nframes, q));
+                HIP_TRY(vk_launch_box_decimate_pair(d_ref, d_dis, fs, rs, e->w, e->h, e->ssim_f, e->ssim_ref, e->ssim_dis, e->ssim_w, e->ssim_h, nframes, q));
                 sr = e->ssim_ref; sd = e->ssim_dis;
             } else if (rs != e->w || fs != (size_t)e->w * e->h) {
                 return fail("ssim at decimation factor 1 needs dense input planes");
             }
-            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, 0, e->partials + e->part_off_ssim, q));
+            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, 0, e->partials + e->part_off_ssim, nullptr, q));
         }
         if (e->m_ms) {
             if (rs != e->w || fs != (size_t)e->w * e->h) return fail("ms_ssim needs dense input planes");
             const float *cr0 = d_ref, *cd0 = d_dis;
             for (int i = 0; i < 5; ++i) {
-                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, i < 4 ? 1 : 0, e->partials + e->part_off_ms[i], q));   // ms_ssim.c:62-64: alpha = 0 below the last level
+                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, i < 4 ? 1 : 0, e->partials + e->part_off_ms[i],   // ms_ssim.c:62-64: alpha = 0 below the last level
+                                            i == 0 && psnr_fused ? e->partials + e->part_off_psnr : nullptr, q));
                 if (i < 4) {
                     HIP_TRY(vk_launch_lpf_decimate(cr0, cd0, (size_t)e->ms_w[i] * e->ms_h[i], e->ms_w[i], e->ms_w[i], e->ms_h[i],
                                                    e->ms_ref[i + 1], e->ms_dis[i + 1], e->ms_w[i + 1], e->ms_h[i + 1], nframes, q));
@@ -362,7 +365,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) HIP_TRY(hipStreamWaitEvent(s_join, e->ev_iqa, 0));
     vk_reduce_table tab;
     int q = fill_reduce_table(e, &tab);
-    tab.d[q++] = { e->part_off_psnr, e->m_psnr ? e->tiles_psnr : 0, 1, 0 };
+    tab.d[q++] = { e->part_off_psnr, e->m_psnr ? (psnr_fused ? e->tiles_ms[0] : e->tiles_psnr) : 0, 1, 0 };
     for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c };
     for (int i = 0; i < 5; ++i)
         for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ms[i], e->m_ms ? e->tiles_ms[i] : 0, 4, c };
@@ -639,8 +642,8 @@ static int enable_metrics_impl(vmaf_hip_engine *e, int do_psnr, int do_ssim, int
     }
     // the partial-sum buffer grows by the metric sections
     size_t off = e->part_total;
-    if (!e->tiles_psnr) {
-        e->tiles_psnr = vk_psnr_tiles(e->h); e->part_off_psnr = off; off += B * e->tiles_psnr;
+    if (!e->tiles_psnr) {                                              // room for either producer of the PSNR partial sums
+        e->tiles_psnr = vk_psnr_tiles(e->h); e->part_off_psnr = off; off += B * std::max(e->tiles_psnr, vk_ssim_tiles(e->w, e->h));
     }
     if (do_ansnr && !e->tiles_ansnr) { e->tiles_ansnr = vk_ansnr_tiles(e->w, e->h); e->part_off_ansnr = off; off += B * e->tiles_ansnr * 2; }
     if (do_ssim && !e->tiles_ssim) { e->tiles_ssim = vk_ssim_tiles(e->ssim_w, e->ssim_h); e->part_off_ssim = off; off += B * e->tiles_ssim * 4; }

@@ -1246,6 +1246,55 @@ __global__ __launch_bounds__(256) void box_decimate_kernel(const float *__restri
     dst[((size_t)blockIdx.z * sh + y) * sw + x] = (float)sum;
 }
 
+// The same decimation for f <= BOXR_FMAX with coalesced reads: a wave forms 64 neighbouring outputs of one output row.  Per
+// kernel row it loads the 64 * f consecutive input samples those outputs cover (lane l takes samples l, l + 64, ...), parks
+// them in its quarter of the LDS (one float of padding after every 32: the strided reads that follow then hit 32 different
+// banks) and every lane reads its own f samples back.  box_decimate_kernel lets each lane fetch its window from memory
+// directly, f dwords at a stride of 4 * f bytes per instruction (3 TB/s at 1080p; this one is bound by the plane read).
+// blockIdx.z = 2 * frame + plane: both planes of a pair in one launch.  Same sum: row-major, float products, double sum.
+constexpr int BOXR_FMAX = 8;
+constexpr int BOXR_ROW = 64 * BOXR_FMAX + 64 * BOXR_FMAX / 32;             // floats of LDS per wave
+__global__ __launch_bounds__(256) void box_decimate_rows_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+                                                                size_t src_frame_stride, int src_row_stride, int w, int h, int f,
+                                                                float *__restrict__ oref, float *__restrict__ odis, int sw, int sh)
+{
+    __shared__ float stage[4][BOXR_ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.z >> 1, plane = blockIdx.z & 1;
+    const float *img = (plane ? dis : ref) + (size_t)frame * src_frame_stride;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave;
+    const int uc = f / 2;
+    const float kv = 1.0f / (f * f);
+    const int i0 = blockIdx.x * 64 * f - uc;                                // first input column of the wave's span
+    int col[BOXR_FMAX];
+#pragma unroll
+    for (int k = 0; k < BOXR_FMAX; ++k) col[k] = sym_idx(i0 + lane + 64 * k, w);
+    float *mine = stage[wave];
+    double sum = 0.0;
+    for (int v = 0; v < f; ++v) {                                           // the same trip count in every wave: barriers inside
+        const float *row = img + (size_t)sym_idx(y * f - uc + v, h) * src_row_stride;
+        float a[BOXR_FMAX];
+#pragma unroll
+        for (int k = 0; k < BOXR_FMAX; ++k)
+            if (k < f) a[k] = row[col[k]];
+        __syncthreads();                                                    // the previous row's reads are done
+#pragma unroll
+        for (int k = 0; k < BOXR_FMAX; ++k)
+            if (k < f) {
+                const int j = lane + 64 * k;
+                mine[j + (j >> 5)] = a[k];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BOXR_FMAX; ++u)
+            if (u < f) {
+                const int j = lane * f + u;
+                sum += (double)(mine[j + (j >> 5)] * kv);
+            }
+    }
+    if (x < sw && y < sh) (plane ? odis : oref)[((size_t)frame * sh + y) * sw + x] = (float)sum;
+}
+
 // ms_ssim.c:41-51: 9/7 biorthogonal low-pass, the 2-D table _iqa_decimate applies (81 float taps, row-major),
 // widened to double and kept in memory: the kernel row loop is not unrolled and fetches its 9 coefficients through the
 // scalar cache (81 double literals would not fit the SGPR file and end up in VGPRs)
@@ -1345,9 +1394,12 @@ __global__ __launch_bounds__(256, 4) void lpf_decimate_kernel(const float *__res
 }
 
 // ssim_tools.h: g_gaussian_window_h == g_gaussian_window_v
-constexpr int SS_TW = 64, SS_TH = 16, SS_IW = SS_TW + 10, SS_IH = SS_TH + 10, SS_IP = SS_IW + 2;   // staged 26 x 74 (pitch 76)
-constexpr int SS_SEG = 8;                                      // outputs per thread in the horizontal pass
-static_assert(SS_IH * (SS_TW / SS_SEG) <= 256 && SS_TW * (SS_TH / 4) == 256, "thread maps of ssim_stat_kernel");
+// Tile 32 x 48 outputs: the horizontal pass runs over the tile's 58 rows (58 / 48 = 1.21 x the outputs; a 64 x 16 tile paid
+// 26 / 16 = 1.63 x) on 58 * 4 = 232 of the 256 threads.
+constexpr int SS_TW = 32, SS_TH = 48, SS_IW = SS_TW + 10, SS_IH = SS_TH + 10, SS_IP = SS_IW + 2;   // staged 58 x 42 (pitch 44)
+constexpr int SS_SEG = 8;                                      // outputs per thread in the horizontal pass (one row)
+constexpr int SS_VR = 6;                                       // outputs per thread in the vertical pass (one column)
+static_assert(SS_IH * (SS_TW / SS_SEG) <= 256 && SS_TW * (SS_TH / SS_VR) == 256, "thread maps of ssim_stat_kernel");
 
 // 11-tap window sum.  The reference (iqa/convolve.c:113-143) rounds every product img * k to float and adds the products
 // to a double running sum in tap order; the result is stored as float.  Here the running sum takes the products through
@@ -1372,31 +1424,60 @@ template <int NOUT> __device__ __forceinline__ void ssim_taps(const double *win,
     }
 }
 
+// 1 / d for d well inside the normal range (here: 29 .. 1e5): v_rcp_f64 and two Newton steps, relative error ~1e-16.  The
+// compiler's IEEE division spends 12 fp64 instructions per quotient (scaling, fix-ups for denormals and infinities).
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+
+// sqrt((double)x) for a float x >= 0: v_sqrt_f32 (1 ulp) and one Newton step in double, whose residual x - s0 * s0 is exact
+// (a 48-bit product): relative error ~1e-14; x = 0 gives 0.
+__device__ __forceinline__ double sqrt_of_float(float x)
+{
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float r0 = s0 > 0.0f ? __builtin_amdgcn_rcpf(s0) : 0.0f;
+    const double sd = (double)s0;
+    const double e = __builtin_fma(-sd, sd, (double)x);
+    return __builtin_fma(e, 0.5 * (double)r0, sd);
+}
+
 // _iqa_ssim with default arguments (iqa/ssim_tools.c:92-243) on dense planes [frame][h][w]: "valid" 11-tap
 // separable Gaussian of {ref, cmp, ref^2, cmp^2, ref*cmp} (horizontal pass first, iqa/convolve.c:113-143), sigma,
 // l / c / s per pixel in double, four sums per workgroup: sum(l*c*s), sum(l), sum(c), sum(s).
 // Horizontal pass: thread = (row, 8 outputs), the 18-sample windows of ref and cmp in registers, products formed
-// there; vertical pass: thread = (column, 4 outputs) with a 14-sample register window per quantity.
+// there; vertical pass: thread = (column, 6 outputs) with a 16-sample register window per quantity.
 // CS_ONLY: the MS-SSIM levels 0..3, whose luminance term carries the exponent 0 (ms_ssim.c:62-64: pow(l, 0) = 1 whatever l
 // is): only sum(c) and sum(s) are formed, the l division is skipped and the l*c*s / l sums stay 0.
-template <bool CS_ONLY>
-__global__ __launch_bounds__(256, 4) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
-                                                        double *__restrict__ partial)
+// PSNR: the launch on the full-resolution planes (MS-SSIM level 0) also forms the PSNR noise sum of psnr.c:37-50,
+// sum (double)(float)(diff * diff) over EVERY pixel of the plane, from the samples it stages anyway (psnr_kernel reads both
+// planes again: 0.36 ms per 120 frames of 1080p).  A workgroup adds the pixels of its own 32 x 48 rectangle; the tiles
+// cover the valid area (w - 10) x (h - 10) only, so the last tile of a row / column also takes the up to 10 columns / rows
+// behind its rectangle, which its staged halo holds.
+template <bool CS_ONLY, bool PSNR>
+__global__ __launch_bounds__(256, 3) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
+                                                        double *__restrict__ partial, double *__restrict__ psnr_partial)
 {
     // one LDS area, used twice: the staged input tiles (rt, ct) until every thread of the horizontal pass holds its
-    // windows in registers, then the five horizontally filtered planes (hc) - 33 KB instead of 49: four workgroups per CU
+    // windows in registers, then the five horizontally filtered planes (hc) - 37 KB; 150 VGPRs: three workgroups per CU
     __shared__ __attribute__((aligned(16))) float smem[5 * SS_IH * SS_TW];
     static_assert(2 * SS_IH * SS_IP <= 5 * SS_IH * SS_TW, "the staged tiles fit the area of the filtered planes");
     float *rt = smem, *ct = smem + SS_IH * SS_IP;
     float (*hc)[SS_IH * SS_TW] = reinterpret_cast<float (*)[SS_IH * SS_TW]>(smem);
-    __shared__ double red[16];
+    __shared__ double red[16], red_psnr[4];
     const int tid = threadIdx.x;
     const int vw = w - 10, vh = h - 10;                              // valid output size
     const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
     const float *fr = ref + (size_t)blockIdx.z * w * h, *fc = cmp + (size_t)blockIdx.z * w * h;
+    const size_t tile = (size_t)blockIdx.z * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x;
     {   // all global loads of a thread in flight before its first LDS write
         constexpr int N = SS_IH * SS_IW, IT = (N + 255) / 256;
         float a[IT], b[IT];
+        double noise[1] = { 0.0 };
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int idx = tid + it * 256;
@@ -1414,10 +1495,17 @@ __global__ __launch_bounds__(256, 4) void ssim_stat_kernel(const float *__restri
                 const int ly = idx / SS_IW, lx = idx - ly * SS_IW;
                 rt[ly * SS_IP + lx] = a[it];
                 ct[ly * SS_IP + lx] = b[it];
+                if (PSNR) {
+                    const bool mine = (lx < SS_TW || blockIdx.x == gridDim.x - 1) && (ly < SS_TH || blockIdx.y == gridDim.y - 1) &&
+                                      x0 + lx < w && y0 + ly < h;
+                    const float diff = a[it] - b[it];
+                    if (mine) noise[0] += (double)(diff * diff);
+                }
             }
         }
+        if (PSNR) block_reduce_store<1, 4>(noise, red_psnr, psnr_partial + tile);   // its barrier is the one the tiles need
     }
-    __syncthreads();
+    if (!PSNR) __syncthreads();
     const bool hthread = tid < SS_IH * (SS_TW / SS_SEG);
     const int row = hthread ? tid / (SS_TW / SS_SEG) : 0, seg = hthread ? tid - row * (SS_TW / SS_SEG) : 0;
     float a[SS_SEG + 10], b[SS_SEG + 10];
@@ -1452,17 +1540,17 @@ __global__ __launch_bounds__(256, 4) void ssim_stat_kernel(const float *__restri
     const float C1 = (K1 * L) * (K1 * L), C2 = (K2 * L) * (K2 * L);
     double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
     {
-        const int ox = tid & (SS_TW - 1), oy0 = (tid / SS_TW) * 4;
-        float m[5][4];
+        const int ox = tid & (SS_TW - 1), oy0 = (tid / SS_TW) * SS_VR;
+        float m[5][SS_VR];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            double win[14];
+            double win[SS_VR + 10];
 #pragma unroll
-            for (int k = 0; k < 14; ++k) win[k] = (double)hc[q][(oy0 + k) * SS_TW + ox];
-            ssim_taps<4>(win, m[q]);
+            for (int k = 0; k < SS_VR + 10; ++k) win[k] = (double)hc[q][(oy0 + k) * SS_TW + ox];
+            ssim_taps<SS_VR>(win, m[q]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SS_VR; ++j) {
             if (x0 + ox < vw && y0 + oy0 + j < vh) {
                 const float ref_mu = m[0][j], cmp_mu = m[1][j];
                 float rss = m[2][j], css = m[3][j], sb = m[4][j];
@@ -1471,19 +1559,21 @@ __global__ __launch_bounds__(256, 4) void ssim_stat_kernel(const float *__restri
                 rss = (float)((0.0 > rss) ? 0.0 : rss);
                 css = (float)((0.0 > css) ? 0.0 : css);
                 sb -= ref_mu * cmp_mu;
-                const double srsc = sqrt((double)(rss * css));
-                const double c = (2.0 * srsc + C2) / (double)(rss + css + C2);
-                const double s_ = (sb + C2 / 2.0) / (srsc + C2 / 2.0);
+                // the reference's sqrt() and divisions are IEEE double; the ones here agree with them to ~1e-14 relative
+                // (a per-pixel term of size <= 1 entering a mean: far below the 1e-7 of the window sums)
+                const double srsc = sqrt_of_float(rss * css);
+                const double c = (2.0 * srsc + C2) * rcp_newton((double)(rss + css + C2));
+                const double s_ = (sb + C2 / 2.0) * rcp_newton(srsc + C2 / 2.0);
                 acc[2] += c; acc[3] += s_;
                 if (!CS_ONLY) {
-                    const double l = (2.0 * ref_mu * cmp_mu + C1) / (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
+                    const double l = (2.0 * ref_mu * cmp_mu + C1) * rcp_newton((double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1));
                     acc[0] += l * c * s_;
                     acc[1] += l;
                 }
             }
         }
     }
-    block_reduce_store<4, 4>(acc, red, partial + ((size_t)blockIdx.z * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x) * 4);
+    block_reduce_store<4, 4>(acc, red, partial + tile * 4);
 }
 
 // ANSNR (ansnr.c:44-104 with the 2-D filters of ansnr_tools.c:36-58, :159-199): ref through the 3x3 binomial, dis
@@ -1721,6 +1811,20 @@ hipError_t vk_launch_box_decimate(const float *src, size_t src_frame_stride, int
     return hipGetLastError();
 }
 
+// both planes of every pair; f = 2 .. 8 through the coalesced kernel, larger factors (8K and up) through the plain one
+hipError_t vk_launch_box_decimate_pair(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h, int f,
+                                       float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s)
+{
+    static const int rows_env = getenv("VMAF_HIP_BOX_ROWS") ? atoi(getenv("VMAF_HIP_BOX_ROWS")) : 1;    // 0: A/B measurements
+    if (f > BOXR_FMAX || !rows_env) {
+        hipError_t err = vk_launch_box_decimate(ref, src_frame_stride, src_row_stride, w, h, f, oref, sw, sh, nframes, s);
+        return err != hipSuccess ? err : vk_launch_box_decimate(dis, src_frame_stride, src_row_stride, w, h, f, odis, sw, sh, nframes, s);
+    }
+    box_decimate_rows_kernel<<<dim3((sw + 63) / 64, (sh + 3) / 4, 2 * nframes), 256, 0, s>>>(ref, dis, src_frame_stride, src_row_stride, w, h, f,
+                                                                                           oref, odis, sw, sh);
+    return hipGetLastError();
+}
+
 hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h,
                                   float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s)
 {
@@ -1730,11 +1834,15 @@ hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src
 }
 
 // ref, cmp: dense planes [nframes][h][w]; partial receives vk_ssim_tiles(w, h) * 4 doubles per frame
-hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, double *partial, hipStream_t s)
+// psnr_partial: null, or vk_ssim_tiles(w, h) doubles per frame for the PSNR noise sums of the same planes (cs_only launches)
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, double *partial,
+                               double *psnr_partial, hipStream_t s)
 {
     const dim3 g((w - 10 + SS_TW - 1) / SS_TW, (h - 10 + SS_TH - 1) / SS_TH, nframes);
-    if (cs_only) ssim_stat_kernel<true><<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
-    else ssim_stat_kernel<false><<<g, 256, 0, s>>>(ref, cmp, w, h, partial);
+    if (psnr_partial && !cs_only) return hipErrorInvalidValue;      // the fused PSNR sum exists for MS-SSIM level 0 only
+    if (psnr_partial) ssim_stat_kernel<true, true><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, psnr_partial);
+    else if (cs_only) ssim_stat_kernel<true, false><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, nullptr);
+    else ssim_stat_kernel<false, false><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, nullptr);
     return hipGetLastError();
 }
 
