@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off randomized parity sweep on the GPU box: random frame sizes (incl. sizes around the tile pitches of the
-kernels: 48x32 VIF, 61x14 ADM coefficients, 60x32 motion), both summation orders, against the CPU oracle.
+kernels: 48x32 and 240x8 VIF, 61x14 ADM coefficients, 60x32 motion), both summation orders, against the CPU oracle.
     python tools/fuzz_parity.py [cases=80] [seed=1]
 Prints the worst relative atom error and the worst absolute feature error; exits 1 on a tolerance breach."""
 import os
@@ -20,9 +20,11 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 80
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     special = [32, 33, 47, 48, 49, 60, 61, 64, 95, 96, 97, 120, 122, 123, 128, 176, 192, 244, 245, 256]
+    wide = [240, 248, 256, 264, 304, 320, 328, 400, 472, 480, 488, 496, 552, 640, 720, 728, 736]   # workgroup-wide VIF tiles, narrow last tiles
     worst_rel, worst_feat, bad = 0.0, 0.0, 0
     for c in range(cases):
-        w = int(rng.choice(special)) if rng.random() < 0.5 else int(rng.integers(32, 420))
+        u = rng.random()
+        w = int(rng.choice(special)) if u < 0.3 else int(rng.choice(wide)) if u < 0.65 else int(rng.integers(32, 420))
         h = int(rng.choice(special)) if rng.random() < 0.5 else int(rng.integers(32, 300))
         bits = 10 if rng.random() < 0.25 else 8
         order = "avx" if rng.random() < 0.6 else "scalar"
