@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--repeat", type=int, default=0,
                     help="how many times the distinct synthetic frames are tiled into one batch (default: the workload's own, "
                          "4 at 1080p = 120 frames per step; 1 = 30 frames per step)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="use only the first N distinct synthetic frames (with --repeat 1: N frames per step; batch-size experiments)")
     ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
     args = ap.parse_args()
 
@@ -215,6 +217,8 @@ def main():
     W, H, BITS, DISTINCT, REPEAT = WORKLOADS[args.workload]
     if args.repeat > 0:
         REPEAT = args.repeat
+    if args.distinct > 0:
+        DISTINCT = min(DISTINCT, args.distinct)
     FRAMES_PER_STEP = DISTINCT * REPEAT
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
