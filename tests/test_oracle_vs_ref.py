@@ -50,10 +50,11 @@ def test_csf_factors_match_survey_values():
     assert np.allclose(oracle.csf_rfactors(), want, rtol=2e-6)
 
 
-@pytest.mark.parametrize("w,h,bits", [(576, 324, 8), (200, 180, 8), (577, 325, 10), (1280, 720, 8), (1083, 769, 8)])
+@pytest.mark.parametrize("w,h,bits", [(576, 324, 8), (200, 180, 8), (577, 325, 10), (1280, 720, 8), (1083, 769, 8),
+                                      (1030, 520, 8), (1301, 1281, 10), (2050, 2062, 8)])    # decimation factors 2, 5, 8
 def test_psnr_ssim_ms_ssim_bit_exact(w, h, bits):
     """oracle/iqa_oracle.c against psnr.c / ssim.c / ms_ssim.c + iqa/ compiled from the reference: SSIM decimation
-    factors 1, 3 (720p, odd-sized kernel) and 3 on odd dimensions (sw = w/f + (w&1)), the 10-bit PSNR peak."""
+    factors 1, 3 (720p, odd-sized kernel), 3 on odd dimensions (sw = w/f + (w&1)), 2, 5 and 8, the 10-bit PSNR peak."""
     r, d = synth.make_clip(w, h, 1, bits=bits, seed=w + h)
     r, d = synth.to_luma_f32(r, bits)[0], synth.to_luma_f32(d, bits)[0]
     assert oracle.psnr(r, d, bits) == oracle.ref_psnr(r, d, bits)
