@@ -182,6 +182,9 @@ class Result:
 
 
 # ---------------------------------------------------------------------------------- scoring
+PREAD_PLANES = os.environ.get('VMAF_HIP_PY_PREAD', '1') not in ('', '0')     # 0: copy out of the memory map instead
+
+
 class LumaFile:
     """A raw YUV file seen as its luma planes, without reading it: a memory map plus the frame geometry.  The reference
     reads one frame at a time (feature/src/common/frame.c:26-129: Y plane, then fread-skips the chroma); here a batch of
@@ -199,6 +202,12 @@ class LumaFile:
         if total - self.frames * self.frame_samples >= n:
             self.frames += 1                               # a last frame with short chroma is still scored (frame.c:83-87)
         self.mm = np.memmap(path, dtype=self.dtype, mode='r') if total else np.zeros(0, self.dtype)
+        self.fd = os.open(path, os.O_RDONLY) if total and PREAD_PLANES else -1
+
+    def __del__(self):
+        if getattr(self, 'fd', -1) >= 0:
+            os.close(self.fd)
+            self.fd = -1
 
     def __len__(self):
         return self.frames
@@ -208,6 +217,19 @@ class LumaFile:
         n = stop - start
         if out is None:
             out = np.empty((n, self.h, self.w), self.dtype)
+        if self.fd >= 0 and out.flags.c_contiguous:
+            # positional reads straight into the (page-locked) destination: no page faults on a mapping, no GIL while the
+            # kernel copies, and a frame counts when its luma is complete (frame.c:83-87), so every read is a full plane
+            size, step = self.n * self.dtype.itemsize, self.frame_samples * self.dtype.itemsize
+            for f in range(start, stop):
+                buf = memoryview(out[f - start]).cast('B')
+                got = 0
+                while got < size:
+                    k = os.preadv(self.fd, [buf[got:]], f * step + got)
+                    if k <= 0:
+                        raise IOError('short read in frame %d' % f)
+                    got += k
+            return out[:n]
         whole = min(stop, len(self.mm) // self.frame_samples)        # frames whose chroma is complete too
         if whole > start:
             v = self.mm[start * self.frame_samples:whole * self.frame_samples].reshape(whole - start, self.frame_samples)
