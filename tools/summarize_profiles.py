@@ -66,6 +66,27 @@ def main():
     met = glob.glob(os.path.join(src, "stats_metrics", "**", "*kernel_stats.csv"), recursive=True)
     if met:
         shutil.copy(met[0], os.path.join(dst, f"{tag}_kernel_stats_metrics.csv"))
+    # the metric kernels launch at several plane sizes (MS-SSIM levels): one row per (kernel, grid), counters and the duration
+    # of the same dispatches; issue per clock = wave-level VALU instructions / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)
+    mfiles = glob.glob(os.path.join(src, "pmc_metrics", "**", "*counter_collection.csv"), recursive=True)
+    if mfiles:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(mfiles[0])):
+            k = short(r["Kernel_Name"])
+            if not any(x in k for x in ("ssim", "lpf", "box", "psnr")):
+                continue
+            key = (k, int(r["Grid_Size"]))
+            agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[key]["us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        cols = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]
+        with open(os.path.join(dst, f"{tag}_metrics_counters.csv"), "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(["kernel", "grid_threads", "launches", "us_under_counters"] + cols + ["valu_wave_insts_per_cycle_per_simd", "lds_conflict_frac"])
+            for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]["us"])):
+                m = {c: sum(v[c]) / len(v[c]) if v[c] else 0.0 for c in cols}
+                per_clk = m["SQ_INSTS_VALU"] / 1024 / (m["GRBM_GUI_ACTIVE"] / 8) if m["GRBM_GUI_ACTIVE"] else 0.0
+                wr.writerow([k, g, len(v["SQ_INSTS_VALU"]), round(sum(v["us"]) / len(v["us"]), 1)] + [int(m[c]) for c in cols] +
+                            [round(per_clk, 3), round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_WAVE_CYCLES"], 4) if m["SQ_WAVE_CYCLES"] else ""])
     ser = glob.glob(os.path.join(src, "stats_serial", "**", "*kernel_stats.csv"), recursive=True)
     dur = {}
     if ser:
