@@ -2,8 +2,9 @@
 the CPU oracle on the same seeded inputs.
 
 Tolerances (BASELINE.json north_star): per-frame features within 1e-4 absolute of the reference C
-code, aggregate VMAF within 1e-3.  The kernels keep the reference's scalar tap order, so the raw
-atoms are additionally held to 2e-6 relative (only the final plane sums are ordered differently).
+code, aggregate VMAF within 1e-3.  The kernels keep the reference's tap orders, so the raw atoms are
+additionally held to 2e-6 relative (only the final VIF / ADM plane sums are ordered differently) and the
+`motion` atom, whose sum the kernel orders as motion.c does, to equality.
 """
 import os
 
@@ -30,6 +31,9 @@ def _check(got, want, what=""):
         g, w = got[:, k], want[:, k]
         tol = ATOM_RTOL * np.maximum(1.0, np.abs(w))
         assert np.all(np.abs(g - w) <= tol), f"{what} atom {name}: got {g} want {w}"
+    # motion is the one plane sum that reaches the model directly: the kernel adds it in the reference's own order
+    # (motion.c:44-60: fp32 per row, left to right, then the rows top to bottom), so the atom is the reference's bit for bit
+    assert np.array_equal(got[:, 10], want[:, 10]), f"{what} motion: got {got[:, 10]!r} want {want[:, 10]!r}"
     fg, fw = _feats(got), _feats(want)
     for k in ("adm2", "motion", "motion2", "vif_scale0", "vif_scale1", "vif_scale2", "vif_scale3",
               "adm_scale0", "adm_scale1", "adm_scale2", "adm_scale3", "vif"):

@@ -256,7 +256,7 @@ int fill_reduce_table(const Geometry *g, vk_reduce_table *tab)
         for (int c = 0; c < 2; ++c) tab->d[q++] = { g->part_off_vif[sc], g->tiles_vif[sc], 2, c };
     for (int sc = 0; sc < 4; ++sc)
         for (int c = 0; c < 6; ++c) tab->d[q++] = { g->part_off_adm[sc], g->tiles_adm[sc], 6, c };
-    tab->d[q++] = { g->part_off_mot, g->tiles_mot, 1, 0 };
+    tab->d[q++] = { g->part_off_mot, 1, g->tiles_mot, 0 };    // one value per frame: motion_total_kernel's fp32 total
     return q;
 }
 
@@ -342,7 +342,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     HIP_TRY(hipEventRecord(e->ev_adm, e->s_adm));
 
     // ---- motion (combo.c:309-326) on s_mot
-    HIP_TRY(vk_launch_motion(e->order, d_ref, fs, rs, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
+    HIP_TRY(vk_launch_motion(e->order, d_ref, 4, fs * 4, rs * 4, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
                              e->partials + e->part_off_mot, e->s_mot));
     HIP_TRY(hipEventRecord(e->ev_mot, e->s_mot));
     e->carry_cur = 1 - e->carry_cur;
@@ -906,7 +906,7 @@ int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t r
     if (row_stride_bytes % 4 || row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
     HIP_TRY(hipSetDevice(e->device));
     // one-frame motion launch without predecessor: only its carry_out side effect is used
-    HIP_TRY(vk_launch_motion(e->order, d_ref, 0, (int)(row_stride_bytes / 4), e->w, e->h, 1, 0, e->carry[e->carry_cur],
+    HIP_TRY(vk_launch_motion(e->order, d_ref, 4, 0, (int)row_stride_bytes, e->w, e->h, 1, 0, e->carry[e->carry_cur],
                              e->carry[1 - e->carry_cur], e->partials + e->part_off_mot, e->s_main));
     e->carry_cur = 1 - e->carry_cur;
     e->carry_valid = true;
@@ -997,7 +997,7 @@ int vmaf_hip_extract_device_noalloc(int device, void *stream, const float *d_ref
     PlaneCursor ac = { d_ref, d_dis, fs, rs };
     for (int sc = 0; sc < 4; ++sc)
         if (launch_adm_scale(&g, &L.b, conv_order, sc, &ac, nframes, s)) return 1;
-    HIP_TRY(vk_launch_motion(conv_order, d_ref, fs, rs, width, height, nframes, 0, L.carry, L.carry, L.b.partials + g.part_off_mot, s));
+    HIP_TRY(vk_launch_motion(conv_order, d_ref, 4, fs * 4, rs * 4, width, height, nframes, 0, L.carry, L.carry, L.b.partials + g.part_off_mot, s));
     vk_reduce_table tab;
     int q = fill_reduce_table(&g, &tab);
     for (; q < VK_NSUMS; ++q) tab.d[q] = { 0, 0, 1, 0 };          // optional metrics: not computed here

@@ -42,8 +42,10 @@ hipError_t vk_launch_adm_scale(int scale, int order, const float *ref, const flo
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
                                double *partial, hipStream_t s);
-hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
-                            const float *carry_in, float *carry_out, double *partial, hipStream_t s);
+// ref: the caller's picture; sample_bytes 4 = fp32 planes, 1 = 8-bit samples, 2 = little-endian 16-bit words (value / 4.0),
+// widened in the kernel's loads (file_io.c:112-116,159-163).  partial: vk_motion_tiles() doubles per frame, [0] = the total
+hipError_t vk_launch_motion(int order, const void *ref, int sample_bytes, size_t frame_stride_bytes, int row_stride_bytes, int w, int h,
+                            int nframes, int has_carry, const float *carry_in, float *carry_out, double *partial, hipStream_t s);
 // raw luma (1 or 2 bytes per sample, 2 = little-endian words / 4.0) -> dense fp32 planes [nframes][h][w]
 hipError_t vk_launch_widen(const void *src, int bytes_per_sample, size_t src_row_bytes, size_t src_frame_bytes, float *dst,
                            int w, int h, int nframes, hipStream_t s);

@@ -196,6 +196,30 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voffset_
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voffset_bytes, soffset_bytes, 0));
 }
 
+// One luma sample of the caller's picture as the float the reference's readers deliver (file_io.c:112-116, 159-163):
+//   float          the planes of the read_frame contract, as they are
+//   unsigned char  (float)px                       read_image_b2s
+//   unsigned short (float)px / 4.0 = px * 0.25f    read_image_w2s (little-endian words, no masking to 10 bits); exact
+// The kernels that read the picture (VIF scale 0, ADM scale 0, motion) are templated on the sample type, so raw 8/16-bit
+// luma is widened in the load and never exists as fp32 planes in HBM.  x = sample index in the row, row offset in bytes.
+template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t sample_rsrc(const T *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ float load_px(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes);
+template <> __device__ __forceinline__ float load_px<float>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, x * 4, row_off_bytes, 0));
+}
+template <> __device__ __forceinline__ float load_px<unsigned char>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
+{
+    return (float)__builtin_amdgcn_raw_buffer_load_b8(r, x, row_off_bytes, 0);
+}
+template <> __device__ __forceinline__ float load_px<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
+{
+    return (float)__builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0) * 0.25f;
+}
+
 // ---------------------------------------------------------------- VIF statistic
 // feature/src/vif_tools.c:33-75
 __device__ __forceinline__ float log2f_approx(float x)
@@ -1061,83 +1085,134 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
 }
 
 // ---------------------------------------------------------------- motion
-// One workgroup owns a 60x32 tile and walks through a chunk of consecutive frames (combo.c:309-326,
-// motion.c:44-60): 5-tap blur of the offset ref (convolution.c:78-93, y then x, in the selected tap order),
-// SAD against the previous frame's blurred tile, which stays in registers.  No staging of the picture:
-//   vertical pass    thread = one of the 64 staged columns (60 + 2x2 halo = one wave) x 8 rows; its 12 input
-//                    rows of the NEXT frame are in flight while the current frame is being filtered
-//   horizontal pass  thread = 8 consecutive outputs of one row, read from LDS as three float4
-// The chunk's first workgroup-iteration only rebuilds the blur of the frame before the chunk (chunk 0 takes it
-// from the plane carried over from the previous call); the last frame's tile goes to carry_out.
-// The blurred planes themselves never go to HBM.  One __syncthreads per frame (double-buffered LDS);
-// every wave stores its own SAD partial, so there is no block reduction either.
-constexpr int MO_TW = 60, MO_TH = 32, MO_THREADS = 256;
+// combo.c:309-326 + motion.c:44-60: 5-tap blur of the offset ref (convolution.c:78-93, y then x, in the selected tap
+// order), SAD against the previous frame's blurred picture - summed in the reference's own order: one fp32 accumulator
+// per row, columns left to right (motion.c:48-55), then the row sums top to bottom in fp32 (motion.c:56), so the
+// `motion` atom is bit-identical to the reference's.  motion is the one atom whose plane sum reaches the model directly
+// (VIF and ADM only feed ratios), and on periodic content a differently ordered sum is visibly different.
+//
+// A row's sum is a chain of w dependent additions; the rows and frames are independent chains.  So a WAVE owns a band of
+// 8 rows x a chunk of consecutive frames and marches over the picture from left to right in steps of 60 columns; at
+// every step it walks through its frames (the previous frame's blurred 8x60 tile stays in registers, as the blurred
+// planes themselves never go to HBM).  No workgroup barrier anywhere: the four waves of a workgroup (32 rows) only share
+// their halo rows through the L1.
+//   vertical pass    lane = one of the 64 staged columns (60 + 2x2 halo) x 8 rows; its 12 input rows of the NEXT step
+//                    are in flight while the current one is being filtered
+//   horizontal pass  lane = (row, 8 consecutive outputs), read from the wave's LDS rows as three float4
+//   row chains       the |differences| of four frames wait in the wave's LDS; then lane = (frame, row) adds the 60 values
+//                    of its row one after the other to the row's running sum, which waits in LDS for the next 60
+//                    columns (32 lanes at work; handing the sum from lane to lane inside a row with DPP moves instead
+//                    keeps 8 lanes at work and costs 72 instructions per frame instead of 38)
+// The chunk's first iteration per step only rebuilds the blur of the frame before the chunk (chunk 0 takes it from the
+// plane carried over from the previous call); the last frame's tiles go to carry_out.  motion_total_kernel then adds
+// the row sums of every frame in order.
+constexpr int MO_TW = 60, MO_THREADS = 256;
 constexpr int MO_CW = MO_TW + 4;                             // staged columns x0-2 .. x0+61
-constexpr int MO_RPT = MO_TH / (MO_THREADS / 64);            // rows per thread, vertical pass (8)
-constexpr int MO_OPT = 8;                                    // outputs per thread, horizontal pass
-constexpr int MO_VP = MO_CW + 4;                             // LDS row pitch: successive rows start 4 banks apart
 constexpr int MO_WAVES = MO_THREADS / 64;
-static_assert(MO_CW == 64 && MO_TH * (MO_CW / MO_OPT) == MO_THREADS, "thread maps");
+constexpr int MO_BH = 8;                                     // rows per wave
+constexpr int MO_TH = MO_BH * MO_WAVES;                      // rows per workgroup
+constexpr int MO_OPT = 8;                                    // outputs per lane, horizontal pass
+constexpr int MO_VP = MO_CW + 4;                             // LDS row pitch: successive rows start 4 banks apart
+constexpr int MO_CMAX = 8;                                   // longest chunk of frames (running sums in LDS)
+constexpr int MO_G = 4;                                      // frames per group of row chains: MO_G x 8 rows = 32 lanes at work
+constexpr int MO_AP = MO_TW + 1;                             // row pitch of the parked |differences|: odd, so that the 32 lanes of
+                                                             // a chain step read 32 different banks
+static_assert(MO_CW == 64 && MO_BH * (MO_CW / MO_OPT) == 64, "lane maps");
 
-template <int ORDER>
-__global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restrict__ ref, size_t frame_stride, int row_stride,
+// Per-wave state of one step (60 columns) of the march
+struct MotionStep {
+    int x0;
+    bool vcol_avx, v_all_avx, h_all_avx;
+    float prev[MO_OPT], live[MO_OPT];
+};
+
+template <int ORDER, typename T>
+__global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict__ ref, size_t frame_stride_bytes, int row_stride_bytes,
                                                             int w, int h, int nframes, int chunk, int has_carry,
                                                             const float *__restrict__ carry_in, float *__restrict__ carry_out,
-                                                            double *__restrict__ partial)
+                                                            float *__restrict__ rowsum, size_t rowsum_stride)
 {
-    __shared__ __attribute__((aligned(16))) float v_s[2][MO_TH * MO_VP];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntx = (w + MO_TW - 1) / MO_TW;
-    const int tile = xcd_tile_index(), ntiles = gridDim.x;        // neighbouring tiles share cache lines: keep them on one XCD
-    const int x0 = (tile % ntx) * MO_TW, y0 = (tile / ntx) * MO_TH;
-    const int f_begin = blockIdx.y * chunk, f_end = min(nframes, f_begin + chunk);
+    __shared__ __attribute__((aligned(16))) float v_all[MO_WAVES][MO_BH * MO_VP];
+    __shared__ float acc_all[MO_WAVES][MO_CMAX * MO_BH];
+    __shared__ float ad_all[MO_WAVES][MO_G * MO_BH * MO_AP];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *vb = v_all[wv], *acc_s = acc_all[wv], *adb = ad_all[wv];
+    // (band, chunk) from the flat workgroup index, bands fastest, through the XCD-aware order: the workgroups one XCD receives
+    // are vertical neighbours of one chunk, whose halo rows then meet in that XCD's L2
+    const int item = xcd_tile_index(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int ck = __builtin_amdgcn_readfirstlane(item / (int)gridDim.x), band = item - ck * (int)gridDim.x;
+    const int vy0 = band * MO_TH + wv * MO_BH;                        // first row of this wave (wave-uniform)
+    if (vy0 >= h) return;                                             // no barrier below: a wave may leave alone
+    const int f_begin = ck * chunk, f_end = min(nframes, f_begin + chunk);
+    // warm-up iteration: blur only.  (readfirstlane: the compiler forms a saturating subtraction, which only the vector
+    // ALU has, and every buffer load of a frame addressed through it would go through a waterfall loop)
+    const int f_first = __builtin_amdgcn_readfirstlane(f_begin == 0 ? 0 : f_begin - 1);
 
-    // vertical-pass identity
-    const int xc = mirror_idx(x0 - 2 + lane, w);
-    const int vy0 = y0 + wv * MO_RPT;                                 // first output row of this wave
-    const bool vcol_avx = ORDER == ORDER_AVX && avx_vcol_ok(xc, w);
-    int roff[MO_RPT + 4];                                             // one plane holds < 2^31 floats (engine limit)
+    int roff[MO_BH + 4];                                              // byte offsets of the 12 input rows, wave-uniform (SGPRs)
 #pragma unroll
-    for (int k = 0; k < MO_RPT + 4; ++k) roff[k] = mirror_idx(vy0 - 2 + k, h) * row_stride * 4;      // byte offsets, wave-uniform (SGPRs)
+    for (int k = 0; k < MO_BH + 4; ++k) roff[k] = mirror_idx(vy0 - 2 + k, h) * row_stride_bytes;
+    const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride_bytes;
+    const unsigned char *ref_b = reinterpret_cast<const unsigned char *>(ref);
     // horizontal-pass identity
-    const int hr = tid >> 3, ox0 = (tid & 7) * MO_OPT;
-    const int gy = y0 + hr;
+    const int hr = lane >> 3, strip = lane & 7, ox0 = strip * MO_OPT;
+    const int gy = vy0 + hr;
     const int hend = avx_hcol_end(w, 2);
 
-    float prev[MO_OPT], cur[MO_OPT], in[MO_RPT + 4];
-    int f = f_begin;
-    if (f_begin == 0) {
+    for (int i = lane; i < MO_CMAX * MO_BH; i += 64) acc_s[i] = 0.0f;   // motion.c:49: accum_line = 0
+
+    // The wave's work is a sequence of iterations (step, frame): steps left to right, inside a step the frames f_first ..
+    // f_end - 1.  The input rows of an iteration are requested TWO iterations ahead into one of two register sets (the
+    // launch has few waves per SIMD - its parallelism is rows x chunks, the width is serial - so a wave has to keep
+    // the memory system busy by itself: with one iteration of look-ahead an iteration took as long as a load)
+    int ld_x0 = 0, ld_f = f_first;                                    // load cursor (wave-uniform)
+    auto request = [&](float (&in)[MO_BH + 4]) {
+        // unconditional (past the last iteration the cursor stays on the last step and the rows are loaded for nothing): with
+        // loads under a branch the compiler cannot count the requests in flight and waits for all of them at the first use
+        const int xc = mirror_idx(min(ld_x0, w - 1) - 2 + lane, w);
+        const auto b = sample_rsrc(reinterpret_cast<const T *>(ref_b + (size_t)ld_f * frame_stride_bytes), frame_bytes);
+#pragma unroll
+        for (int k = 0; k < MO_BH + 4; ++k) in[k] = load_px<T>(b, xc, roff[k]);
+        if (++ld_f == f_end) { ld_f = f_first; ld_x0 += MO_TW; }
+    };
+
+    MotionStep st;
+    int f = f_first;
+    st.x0 = 0;
+    auto begin_step = [&]() {
+        // the usual step has every sample in the vector order (convolution_avx.c:799-836 leaves it in the first and last two
+        // rows, the columns from floor8(w) on in the vertical pass, the first two and the last few in the horizontal pass):
+        // decided once per step and wave, so that the frames' loop carries no per-sample masks
+        const int xc = mirror_idx(st.x0 - 2 + lane, w);
+        st.vcol_avx = ORDER == ORDER_AVX && avx_vcol_ok(xc, w);
+        bool hall = true;
 #pragma unroll
         for (int j = 0; j < MO_OPT; ++j) {
-            const int gx = x0 + ox0 + j;
-            prev[j] = (has_carry && ox0 + j < MO_TW && gx < w && gy < h) ? carry_in[(size_t)gy * w + gx] : 0.0f;
+            const int gx = st.x0 + ox0 + j;
+            const bool mine = ox0 + j < MO_TW && gx < w && gy < h;
+            st.live[j] = mine ? 1.0f : 0.0f;
+            st.prev[j] = (f_begin == 0 && has_carry && mine) ? carry_in[(size_t)gy * w + gx] : 0.0f;
+            hall = hall && gx >= 2 && gx < hend;
         }
-    } else {
-        f = f_begin - 1;                                              // warm-up iteration: blur only
+        st.v_all_avx = __all(st.vcol_avx) && avx_row_ok(vy0, h, 2) && avx_row_ok(vy0 + MO_BH - 1, h, 2);
+        st.h_all_avx = __all(hall);
+    };
+    // one iteration; returns false after the last one
+    auto iterate = [&](float (&in)[MO_BH + 4]) -> bool {
+        if (f == f_first) begin_step();
 #pragma unroll
-        for (int j = 0; j < MO_OPT; ++j) prev[j] = 0.0f;
-    }
-    const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
-    {
-        const auto b = frame_rsrc(ref + (size_t)f * frame_stride, frame_bytes);
+        for (int k = 0; k < MO_BH + 4; ++k) in[k] = in[k] + -128.0f;                  // offset_image, combo.c:236
+        wave_lds_sync();                                                              // the previous iteration's reads stay before these writes
+        if (ORDER != ORDER_AVX || st.v_all_avx) {
 #pragma unroll
-        for (int k = 0; k < MO_RPT + 4; ++k) in[k] = buf_load(b, xc * 4, roff[k]);
-    }
-    int buf = 0;
-    for (; f < f_end; ++f, buf ^= 1) {
-        float *vb = v_s[buf];
+            for (int i = 0; i < MO_BH; ++i) vb[i * MO_VP + lane] = taps_sel<5, true, ORDER>(in + i, 1, true);
+        } else {
 #pragma unroll
-        for (int k = 0; k < MO_RPT + 4; ++k) in[k] = in[k] + -128.0f;                 // offset_image, combo.c:236
-#pragma unroll
-        for (int i = 0; i < MO_RPT; ++i)
-            vb[(wv * MO_RPT + i) * MO_VP + lane] = taps_sel<5, true, ORDER>(in + i, 1, vcol_avx && avx_row_ok(vy0 + i, h, 2));
-        __syncthreads();
-        if (f + 1 < f_end) {
-            const auto b = frame_rsrc(ref + (size_t)(f + 1) * frame_stride, frame_bytes);
-#pragma unroll
-            for (int k = 0; k < MO_RPT + 4; ++k) in[k] = buf_load(b, xc * 4, roff[k]);
+            for (int i = 0; i < MO_BH; ++i)
+                vb[i * MO_VP + lane] = taps_sel<5, true, ORDER>(in + i, 1, st.vcol_avx && avx_row_ok(vy0 + i, h, 2));
         }
+        wave_lds_sync();
+        request(in);                                                                  // this set is free: the iteration after the next
         float win[MO_OPT + 4];
         {
             const float4 *src = reinterpret_cast<const float4 *>(vb + hr * MO_VP + ox0);
@@ -1147,27 +1222,84 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const float *__restr
             win[8] = c.x; win[9] = c.y; win[10] = c.z; win[11] = c.w;
         }
         const bool scored = f >= f_begin && (f > 0 || has_carry);
-        double acc = 0.0;
+        float cur[MO_OPT], ad[MO_OPT];
+        if (ORDER != ORDER_AVX || st.h_all_avx) {
+#pragma unroll
+            for (int j = 0; j < MO_OPT; ++j) cur[j] = taps_sel<5, true, ORDER>(win + j, 1, true);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MO_OPT; ++j) cur[j] = taps_sel<5, true, ORDER>(win + j, 1, st.x0 + ox0 + j >= 2 && st.x0 + ox0 + j < hend);
+        }
 #pragma unroll
         for (int j = 0; j < MO_OPT; ++j) {
-            const int gx = x0 + ox0 + j;
-            cur[j] = taps_sel<5, true, ORDER>(win + j, 1, ORDER == ORDER_AVX && gx >= 2 && gx < hend);
-            if (scored && ox0 + j < MO_TW && gx < w && gy < h) acc += (double)fabsf(prev[j] - cur[j]);
-            prev[j] = cur[j];
+            // columns beyond the tile or the picture add +0.0f (x * 0.0f: the blurred values are finite), which leaves a
+            // non-negative running sum as it is; x * 1.0f is x
+            ad[j] = fabsf(st.prev[j] - cur[j]) * (scored ? st.live[j] : 0.0f);
+            st.prev[j] = cur[j];
         }
         if (f >= f_begin) {
+            // park the |differences| of this frame; every MO_G frames the wave turns to the row chains
+            const int fi = f - f_begin, slot = fi & (MO_G - 1);
+            float *dst = adb + (slot * MO_BH + hr) * MO_AP + ox0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-            if (lane == 0) partial[((size_t)f * ntiles + tile) * MO_WAVES + wv] = acc;
-        }
-    }
-    if (carry_out && f_end == nframes) {
+            for (int j = 0; j < MO_OPT; ++j)
+                if (j < 4 || strip < 7) dst[j] = ad[j];
+            if (slot == MO_G - 1 || f + 1 == f_end) {
+                // motion.c:50-55: accum_line += fabs(..) over the columns in order.  (The reference adds in double and
+                // rounds to float at every step; for one addition of two floats that is the fp32 sum: 53 >= 2*24 + 2.)
+                // lane = (frame of the group, row): its running sum from the previous 60 columns, then 60 additions
+                wave_lds_sync();
+                if (lane < (slot + 1) * MO_BH) {
+                    const int ai = (fi - slot) * MO_BH + lane;
+                    const float *src = adb + lane * MO_AP;
+                    float t = acc_s[ai];
 #pragma unroll
-        for (int j = 0; j < MO_OPT; ++j) {
-            const int gx = x0 + ox0 + j;
-            if (ox0 + j < MO_TW && gx < w && gy < h) carry_out[(size_t)gy * w + gx] = prev[j];
+                    for (int j = 0; j < MO_TW; ++j) t = t + src[j];
+                    acc_s[ai] = t;
+                }
+                wave_lds_sync();
+            }
         }
+        if (++f == f_end) {
+            if (carry_out && f_end == nframes) {
+#pragma unroll
+                for (int j = 0; j < MO_OPT; ++j) {
+                    const int gx = st.x0 + ox0 + j;
+                    if (ox0 + j < MO_TW && gx < w && gy < h) carry_out[(size_t)gy * w + gx] = st.prev[j];
+                }
+            }
+            f = f_first;
+            st.x0 += MO_TW;
+        }
+        return st.x0 < w;
+    };
+
+    float in_a[MO_BH + 4], in_b[MO_BH + 4];
+    request(in_a);
+    request(in_b);
+    while (iterate(in_a) && iterate(in_b)) {}
+
+    wave_lds_sync();
+    for (int i = lane; i < (f_end - f_begin) * MO_BH; i += 64) {
+        const int fi = i >> 3, r = i & 7;
+        if (vy0 + r < h) rowsum[(size_t)(f_begin + fi) * rowsum_stride + vy0 + r] = acc_s[i];
     }
+}
+
+// motion.c:56-59: accum += accum_line over the rows in order, fp32.  One wave per frame: 64 row sums per load, added one
+// after the other (every lane keeps the same running sum).  The total goes to the frame's first partial slot as a double.
+__global__ __launch_bounds__(64) void motion_total_kernel(const float *__restrict__ rowsum, size_t rowsum_stride, int h,
+                                                          double *__restrict__ total, size_t total_stride)
+{
+    const int lane = threadIdx.x;
+    const float *rs = rowsum + (size_t)blockIdx.x * rowsum_stride;
+    float acc = 0.0f;
+    for (int r0 = 0; r0 < h; r0 += 64) {
+        const float v = r0 + lane < h ? rs[r0 + lane] : 0.0f;        // + 0.0f beyond the last row: no change
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    }
+    if (lane == 0) total[(size_t)blockIdx.x * total_stride] = (double)acc;
 }
 
 // ---------------------------------------------------------------- raw luma ingest
@@ -1707,7 +1839,8 @@ int vk_adm_tiles(int w, int h)
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     return ((bw + ADM_TW - 1) / ADM_TW) * ((bh + ADM_TH - 1) / ADM_TH);
 }
-int vk_motion_tiles(int w, int h) { return ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH) * MO_WAVES; }   // partial doubles per frame
+// doubles per frame in the partial buffer: [0] the frame's SAD total (fp32 value), then its h row sums as packed floats
+int vk_motion_tiles(int w, int h) { (void)w; return 1 + (h + 1) / 2; }
 
 hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
@@ -1759,24 +1892,38 @@ hipError_t vk_launch_adm_scale(int scale, int order, const float *ref, const flo
     return hipGetLastError();
 }
 
-hipError_t vk_launch_motion(int order, const float *ref, size_t frame_stride, int row_stride, int w, int h, int nframes, int has_carry,
-                            const float *carry_in, float *carry_out, double *partial, hipStream_t s)
+hipError_t vk_launch_motion(int order, const void *ref, int sample_bytes, size_t frame_stride_bytes, int row_stride_bytes, int w, int h,
+                            int nframes, int has_carry, const float *carry_in, float *carry_out, double *partial, hipStream_t s)
 {
-    // workgroup = (tile, chunk of frames): enough chunks for ~2 resident rounds of workgroups, each chunk
-    // pays one extra blur (of the frame before it), so chunks stay as long as that allows
+    // wave = (band of 8 rows, chunk of frames), marching over the columns (motion_kernel): the picture's width is serial,
+    // so the launch gets its parallelism from rows x chunks.  Every chunk pays one extra blur per step (of the frame before
+    // it): chunks as long as ~6000 waves allow.
     static const int forced = getenv("VMAF_HIP_MOTION_CHUNK") ? atoi(getenv("VMAF_HIP_MOTION_CHUNK")) : 0;
-    const int tiles = ((w + MO_TW - 1) / MO_TW) * ((h + MO_TH - 1) / MO_TH);
-    int nchunks = (4096 + tiles - 1) / tiles;
-    if (nchunks > nframes) nchunks = nframes;
-    int chunk = forced > 0 ? forced : (nframes + nchunks - 1) / nchunks;
-    if (chunk < 1) chunk = 1;
-    const dim3 g(tiles, (nframes + chunk - 1) / chunk, 1);
-    if (order == ORDER_SCALAR)
-        motion_kernel<ORDER_SCALAR><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
-    else if (order == ORDER_FMA)
-        motion_kernel<ORDER_FMA><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
-    else
-        motion_kernel<ORDER_AVX><<<g, MO_THREADS, 0, s>>>(ref, frame_stride, row_stride, w, h, nframes, chunk, has_carry, carry_in, carry_out, partial);
+    const int nbands = (h + MO_TH - 1) / MO_TH, rows8 = (h + MO_BH - 1) / MO_BH;
+    int chunk = forced > 0 ? forced : (int)(((long long)nframes * rows8 + 3071) / 6144);
+    chunk = (chunk + MO_G - 1) / MO_G * MO_G;                      // whole groups of row chains
+    if (chunk < MO_G) chunk = MO_G;
+    if (chunk > MO_CMAX) chunk = MO_CMAX;
+    if (chunk > nframes) chunk = nframes;
+    const int nchunks = (nframes + chunk - 1) / chunk;
+    const dim3 g(nbands, nchunks, 1);
+    const int tiles = vk_motion_tiles(w, h);
+    float *rowsum = reinterpret_cast<float *>(partial + 1);
+    const size_t rs_stride = (size_t)tiles * 2;
+#define MOTION_ARGS frame_stride_bytes, row_stride_bytes, w, h, nframes, chunk, has_carry, carry_in, carry_out, rowsum, rs_stride
+#define MOTION_T(T)                                                                                              \
+    if (order == ORDER_SCALAR) motion_kernel<ORDER_SCALAR, T><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS);  \
+    else if (order == ORDER_FMA) motion_kernel<ORDER_FMA, T><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS);   \
+    else motion_kernel<ORDER_AVX, T><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS)
+    if (sample_bytes == 4) { MOTION_T(float); }
+    else if (sample_bytes == 1) { MOTION_T(unsigned char); }
+    else if (sample_bytes == 2) { MOTION_T(unsigned short); }
+    else return hipErrorInvalidValue;
+#undef MOTION_T
+#undef MOTION_ARGS
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    motion_total_kernel<<<nframes, 64, 0, s>>>(rowsum, rs_stride, h, partial, (size_t)tiles);
     return hipGetLastError();
 }
 
