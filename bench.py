@@ -52,21 +52,22 @@ MODEL = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PATH_BYTES_PER_PX = 26.5        # algorithmic bytes of the whole path per luma pixel
 PATH_FLOP_PER_PX = 620.0       # algorithmic fp32 flops of the whole path per luma pixel
-VIF0_BYTES_PER_PX = 10.0        # dominant kernel: reads the fp32 ref and dis planes once (8 B/px) and writes the
-                                # two decimated planes of the next VIF scale (2 x 4 B / 4 px = 2 B/px)
+VIF0_BYTES_PER_PX = 10.0        # dominant kernel, fp32 input: reads the fp32 ref and dis planes once (8 B/px) and writes the
+                                # two decimated planes of the next VIF scale (2 x 4 B / 4 px = 2 B/px); raw input: 2 x
+                                # sample bytes read instead of 8 (main() sets the figure for the run)
 
 
 VALU_PEAK_WINST = 1024 * 2.4e9 / 2   # wave64 fp32 VALU instructions/s: 256 CUs x 4 SIMDs, one per 2 cycles at 2.4 GHz
                                      # (MI355X_MICROARCH.md: 157 TFLOP/s fp32 vector = this rate x 64 lanes x 2 flop)
 
 
-def committed_profile(frames_per_launch):
+def committed_profile(frames_per_launch, input_kind="raw"):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes (profiles/traffic.json,
     written by tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU runs of this
     bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  {} when no profile matches."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if (t["width"], t["height"]) != (W, H):
+        if (t["width"], t["height"]) != (W, H) or t.get("input", "f32") != input_kind:
             return {}
         k = frames_per_launch / t["frames_per_launch"]
         return {"traffic": int(t["hbm_bytes_per_launch"] * k), "valu": int(t.get("valu_wave_insts_per_launch", 0) * k)}
@@ -212,6 +213,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=0,
                     help="use only the first N distinct synthetic frames (with --repeat 1: N frames per step; batch-size experiments)")
     ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
+    ap.add_argument("--input", choices=["raw", "f32"], default="raw",
+                    help="how the luma planes are resident in HBM before the timed region: raw = the samples as the YUV file holds "
+                         "them (uint8, or uint16 words for 10-bit; widened in the kernels' loads - the headline), f32 = the fp32 planes "
+                         "a read_frame callback delivers (round 1-2's headline, still reported beside it as `f32_input`)")
     args = ap.parse_args()
 
     global W, H, BITS, FRAMES_PER_STEP
@@ -241,13 +246,36 @@ def main():
     dev = torch.device("cuda", local_rank)
     coll_dev = torch.device("cpu") if rehearsal else dev
     B, K = FRAMES_PER_STEP, args.steps
+    global VIF0_BYTES_PER_PX, PATH_BYTES_PER_PX
+    if args.input == "raw":                             # "the first term drops from 8N to 2N/4N"
+        in_bytes = 2.0 * (2 if BITS == 10 else 1)
+        VIF0_BYTES_PER_PX = in_bytes + 2.0
+        PATH_BYTES_PER_PX = 26.5 - 8.0 + in_bytes
 
-    # ---- synthetic clip, resident in HBM as fp32 luma
+    # ---- synthetic clip, resident in HBM: raw luma (uint8 / uint16, as the file holds it) and the fp32 planes of the read_frame contract
     r8, d8 = synth.make_clip(W, H, DISTINCT, bits=BITS, seed=1234)
     ref, dis = synth.to_luma_f32(r8, BITS), synth.to_luma_f32(d8, BITS)
     t_ref = torch.from_numpy(ref).to(dev).repeat(REPEAT, 1, 1).contiguous()
     t_dis = torch.from_numpy(dis).to(dev).repeat(REPEAT, 1, 1).contiguous()
+    BPS = r8.dtype.itemsize
+    as_torch = (lambda a: torch.from_numpy(a)) if BPS == 1 else (lambda a: torch.from_numpy(a.view(np.int16)))   # torch has no uint16 arithmetic; bits only
+    q_ref = as_torch(r8).to(dev).repeat(REPEAT, 1, 1).contiguous()
+    q_dis = as_torch(d8).to(dev).repeat(REPEAT, 1, 1).contiguous()
     torch.cuda.synchronize()
+    raw_in = args.input == "raw"
+
+    def run_batch(e, continue_sequence, out, sync=True, raw=raw_in):
+        if raw:
+            return e.extract_device_raw(q_ref, q_dis, B, BPS, continue_sequence=continue_sequence, out=out, sync=sync)
+        return e.extract_device(t_ref, t_dis, B, continue_sequence=continue_sequence, out=out, sync=sync)
+
+    def pipelined(e, K_, out, first_continues=False, raw=raw_in):
+        """K_ batches, two in flight: batch k is enqueued before batch k-1 is collected"""
+        for k in range(K_):
+            run_batch(e, k > 0 or first_continues, out[k], sync=False, raw=raw)
+            if k > 0:
+                e.sync_oldest()
+        e.sync()
 
     eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order)
     if args.metrics:
@@ -255,7 +283,7 @@ def main():
     atoms = np.zeros((K, B, 20))
     scratch = np.zeros((B, 20))
     for i in range(args.warmup):
-        eng.extract_device(t_ref, t_dis, B, continue_sequence=i > 0, out=scratch)
+        run_batch(eng, i > 0, scratch)
     # untimed warm-up of everything the timed region touches for the first time otherwise: the RCCL communicator
     # (lazy initialisation at the first collective costs seconds) and the fusion call's one-off allocations
     warm = sharding.gather_rows(scratch, dist if world > 1 else None, coll_dev)
@@ -271,10 +299,13 @@ def main():
     k_ms = []
     barrier()
     t0 = time.perf_counter()
-    if rank > 0:
-        eng.motion_seed(t_ref[B - 1])                  # halo: the frame before this rank's range
+    if rank > 0:                                        # halo: the frame before this rank's range
+        if raw_in:
+            eng.motion_seed_device_raw(q_ref[B - 1], BPS)
+        else:
+            eng.motion_seed(t_ref[B - 1])
     for k in range(K):                                  # two batches in flight: batch k is enqueued before batch k-1 is collected
-        eng.extract_device(t_ref, t_dis, B, continue_sequence=(k > 0 or rank > 0), out=atoms[k], sync=False)
+        run_batch(eng, k > 0 or rank > 0, atoms[k], sync=False)
         if k > 0:
             eng.sync_oldest()
             ms = eng.last_kernel_ms(1)
@@ -302,11 +333,11 @@ def main():
         os.environ["VMAF_HIP_SERIAL"] = "1"
         try:
             with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order) as eng1:
-                eng1.extract_device(t_ref, t_dis, B, out=scratch)
+                run_batch(eng1, False, scratch)
                 eng1.arm_timing()
                 xs = []
                 for i in range(40):                    # the first launches after the idle gap of the engine set-up run at ramping clocks
-                    eng1.extract_device(t_ref, t_dis, B, continue_sequence=True, out=scratch)
+                    run_batch(eng1, True, scratch)
                     xs.append(eng1.last_kernel_ms(1))
                 xs = [x for x in xs[16:] if x > 0]
                 excl_ms = float(np.mean(xs)) if xs else None
@@ -322,14 +353,10 @@ def main():
         with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order="fma") as engf:
             fa = np.zeros((K, B, 20))
             for i in range(args.warmup):
-                engf.extract_device(t_ref, t_dis, B, continue_sequence=i > 0, out=scratch)
+                run_batch(engf, i > 0, scratch)
             torch.cuda.synchronize()
             tf0 = time.perf_counter()
-            for k in range(K):
-                engf.extract_device(t_ref, t_dis, B, continue_sequence=k > 0, out=fa[k], sync=False)
-                if k > 0:
-                    engf.sync_oldest()
-            engf.sync()
+            pipelined(engf, K, fa)
             fv, ff = vmaf_amd.predict_from_atoms(fa.reshape(K * B, 20), MODEL, device=local_rank)
             torch.cuda.synchronize()
             tf = time.perf_counter() - tf0
@@ -338,6 +365,23 @@ def main():
                 "value": round(K * B / tf, 2), "unit": "frames/sec", "ms_per_step": round(1e3 * tf / K, 4),
                 "max_abs_feature_diff_vs_headline": float(np.abs(ff - f0).max()),
                 "max_abs_vmaf_diff_vs_headline": float(np.abs(fv - vmaf).max())}
+    other = None
+    if rank == 0 and world == 1 and args.order == "avx" and not args.metrics:
+        # beside the headline: the same loop with the luma resident in HBM in the other form (fp32 planes <-> raw samples)
+        with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order) as engo:
+            oa = np.zeros((K, B, 20))
+            for i in range(args.warmup):
+                run_batch(engo, i > 0, scratch, raw=not raw_in)
+            torch.cuda.synchronize()
+            to0 = time.perf_counter()
+            pipelined(engo, K, oa, raw=not raw_in)
+            vmaf_amd.predict_from_atoms(oa.reshape(K * B, 20), MODEL, device=local_rank)
+            torch.cuda.synchronize()
+            to = time.perf_counter() - to0
+        other = {"value": round(K * B / to, 2), "unit": "frames/sec", "ms_per_step": round(1e3 * to / K, 4),
+                 "atoms_identical_to_headline": bool(np.array_equal(oa, atoms)),
+                 "what": ("fp32 luma planes resident in HBM (the read_frame contract; the headline of rounds 1-2)" if raw_in else
+                          f"raw uint{8 * BPS} luma resident in HBM, widened in the kernels' loads") + ", same loop and fusion, outside the timed region"}
     if rank == 0:
         frames = world * K * B
         fps = frames / elapsed
@@ -345,7 +389,7 @@ def main():
         roof = None
         if kernel_ms:
             achieved = VIF0_BYTES_PER_PX * W * H * B / (kernel_ms * 1e-3) / 1e9
-            prof = committed_profile(B) if args.order == "avx" else {}     # the committed counters are of the default order
+            prof = committed_profile(B, args.input) if args.order == "avx" else {}     # the committed counters are of the default order
             roof = {"bound": "hbm", "kernel": (f"vif_stat_wg_kernel<17> (VIF scale 0, fused, workgroup-wide 240x8 tiles; {args.order} order)" if W % 8 == 0 and W >= 240 else
                                f"vif_stat_avx_kernel<17> / vif_stat_kernel<17> (VIF scale 0, fused, wave-private 48x32 tiles; {args.order} order)"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -370,13 +414,16 @@ def main():
         line = {"metric": "frames/sec (whole node) 1080p VMAF v0.6.1" if args.workload == "1080p" else f"frames/sec (whole node) {args.workload} VMAF v0.6.1", "value": round(fps, 2), "unit": "frames/sec",
                 "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"synthetic {W}x{H} yuv420p {BITS}-bit ref/dis pair, vmaf_v0.6.1, fp32 luma resident in HBM" +
+                "config": {"workload": f"synthetic {W}x{H} yuv420p {BITS}-bit ref/dis pair, vmaf_v0.6.1, " +
+                                       (f"raw uint{8 * BPS} luma resident in HBM (widened to fp32 in the kernels' loads)" if raw_in else "fp32 luma resident in HBM") +
                                        (" + psnr/ssim/ms_ssim" if args.metrics else ""),
                            "frames_per_step_per_gpu": B, "distinct_frames": DISTINCT, "frames_total": frames,
                            "parallelism": f"frame-range x{world}, 1-frame motion halo" if world > 1 else "single GPU"},
                 "mean_vmaf": round(float(np.mean(vmaf)), 4), "roofline": roof}
         if fast:
             line["fast_mode"] = fast
+        if other:
+            line["f32_input" if raw_in else "raw_input"] = other
         if args.order != "avx":
             line["config"]["conv_order"] = args.order
         # the two side figures must never cost the headline line: a full /dev/shm or a missing oracle build is reported, not raised

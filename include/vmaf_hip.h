@@ -121,8 +121,10 @@ int vmaf_hip_engine_sync_oldest(vmaf_hip_engine *e);
  * bytes_per_sample 1 = 8-bit, 2 = 16-bit little-endian words (the *10le formats) - and the GPU does the
  * conversion the reference does on the host while reading: (float)px, or (float)px / 4.0 for words, no masking
  * to 10 bits (feature/src/common/file_io.c:86-172, read_image_b2s / read_image_w2s called from
- * feature/src/common/frame.c:44-78).  A quarter (half) of the fp32 bytes cross PCIe.  Strides in bytes,
- * multiples of bytes_per_sample.  Results are bit-identical to the fp32 calls on the converted planes.
+ * feature/src/common/frame.c:44-78).  The conversion happens in the loads of the kernels that read the picture (VIF
+ * scale 0, ADM scale 0, motion): the samples never exist as fp32 planes in device memory, a quarter (half) of the fp32
+ * bytes cross PCIe and come out of HBM.  (Only the optional metrics, whose kernels take fp32 planes, get a widened copy.)
+ * Strides in bytes, multiples of bytes_per_sample.  Results are bit-identical to the fp32 calls on the converted planes.
  */
 int vmaf_hip_extract_host_raw(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample,
                               size_t row_stride_bytes, size_t frame_stride_bytes, int nframes,
@@ -154,6 +156,7 @@ void vmaf_hip_host_free(void *p);
 int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t row_stride_bytes);
 int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row_stride_bytes);
 int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int bytes_per_sample, size_t row_stride_bytes);
+int vmaf_hip_motion_seed_device_raw(vmaf_hip_engine *e, const void *d_ref, int bytes_per_sample, size_t row_stride_bytes);
 
 /*
  * Optional per-frame metrics of the reference's frame loop (wrapper/src/combo.c:168-230): PSNR

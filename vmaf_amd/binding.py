@@ -59,6 +59,7 @@ def load_library():
                  "vmaf_hip_extract_host_raw_async"):
         getattr(L, name).argtypes = [vp, vp, vp, i, sz, sz, i, i, _dp]
     L.vmaf_hip_motion_seed_host_raw.argtypes = [vp, vp, i, sz]
+    L.vmaf_hip_motion_seed_device_raw.argtypes = [vp, vp, i, sz]
     L.vmaf_hip_engine_enable_metrics.argtypes = [vp, i, i, i, i]
     L.vmaf_hip_engine_enable_ansnr.argtypes = [vp, i]
     L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
@@ -193,17 +194,24 @@ class Engine:
         self.metrics = np.concatenate(rows) if rows else np.zeros((0, N_METRICS))
         return out
 
-    def extract_device_raw(self, d_ref, d_dis, nframes, bytes_per_sample, continue_sequence=False, out=None):
+    def extract_device_raw(self, d_ref, d_dis, nframes, bytes_per_sample, continue_sequence=False, out=None, sync=True):
         """Device-resident raw luma (addresses or torch uint8 / int16 tensors), dense rows."""
         pr = d_ref.data_ptr() if hasattr(d_ref, "data_ptr") else int(d_ref)
         pd = d_dis.data_ptr() if hasattr(d_dis, "data_ptr") else int(d_dis)
         rs = self.w * bytes_per_sample
         if out is None:
             out = np.zeros((nframes, N_ATOMS))
-        if self.L.vmaf_hip_extract_device_raw(self._h, pr, pd, bytes_per_sample, rs, rs * self.h, nframes,
-                                              1 if continue_sequence else 0, out.ctypes.data_as(_dp)):
+        fn = self.L.vmaf_hip_extract_device_raw if sync else self.L.vmaf_hip_extract_device_raw_async
+        if fn(self._h, pr, pd, bytes_per_sample, rs, rs * self.h, nframes, 1 if continue_sequence else 0, out.ctypes.data_as(_dp)):
             raise VmafHipError(_err(self.L))
+        self._keep = ([self._keep[-1]] if self._keep else []) + [(d_ref, d_dis, out)]   # buffers of the calls in flight
         return out
+
+    def motion_seed_device_raw(self, d_ref_frame, bytes_per_sample):
+        """Motion halo from one device-resident raw luma frame (address or torch tensor), dense rows."""
+        p = d_ref_frame.data_ptr() if hasattr(d_ref_frame, "data_ptr") else int(d_ref_frame)
+        if self.L.vmaf_hip_motion_seed_device_raw(self._h, p, bytes_per_sample, self.w * bytes_per_sample):
+            raise VmafHipError(_err(self.L))
 
     # -- device pointers (torch tensors or raw ints) ----------------------------------------------
     def extract_device(self, d_ref, d_dis, nframes, row_stride_bytes=None, frame_stride_bytes=None,

@@ -5,7 +5,8 @@
 //   vif pyramid  scale 1..3: ref + dis planes, (w>>s) x (h>>s) each, B of them      (vif.c:157-186)
 //   adm LL bands level 0..2: ref + dis planes, ceil-halved sizes, B of them         (adm.c:241-247)
 //   carry[2]     blurred ref of the last frame of the previous call, w x h          (combo.c:326)
-//   staging      B un-offset ref + dis planes for the host-pointer entry point
+//   staging      on first use only: raw 8/16-bit planes of a host-pointer raw call, B fp32 ref + dis planes for the fp32
+//                host-pointer entry point (and for the optional metrics when the input is raw luma)
 //   partials     per-block fp64 partial sums of every kernel of the batch
 //   sums         B x VK_NSUMS fp64, copied to pinned host memory
 // The VIF chain, the ADM chain and motion run on three streams and join before the reduction.
@@ -106,7 +107,8 @@ struct vmaf_hip_engine : Geometry, FeatureBuffers {
     float *carry[2] = {};
     int carry_cur = 0;
     bool carry_valid = false;
-    float *stage_ref[kDepth] = {}, *stage_dis[kDepth] = {};      // fp32 planes; [1] allocated on first use by the fp32 host path
+    float *stage_ref[kDepth] = {}, *stage_dis[kDepth] = {};      // fp32 planes, allocated on first use: the fp32 host path, and raw input with metrics on
+    void *seed_buf = nullptr;                                    // one plane for the motion seed of a host frame, on first use
     double *sums_host[kDepth] = {};
 
     // optional metrics (combo.c:168-230): PSNR, SSIM, MS-SSIM on the un-offset planes
@@ -220,8 +222,9 @@ void geometry_init(Geometry *g, int width, int height, int max_batch)
 
 int alloc_planes(float **p, size_t floats) { HIP_TRY(hipMalloc((void **)p, floats * sizeof(float))); return 0; }
 
-// Where a chain reads its current scale from: the caller's planes at scale 0, the pyramid buffers afterwards.
-struct PlaneCursor { const float *ref, *dis; size_t frame_stride; int row_stride; };
+// Where a chain reads its current scale from: the caller's picture at scale 0 (fp32 planes, or raw 8/16-bit luma that the
+// kernels widen in their loads), the fp32 pyramid buffers afterwards.  Strides in samples.
+struct PlaneCursor { const void *ref, *dis; int sample; size_t frame_stride; int row_stride; };
 
 // One VIF scale: statistic + (sc < 3) the next scale's planes, both from one read of the current planes (vif.c:157-269)
 int launch_vif_scale(const Geometry *g, const FeatureBuffers *b, int order, int sc, PlaneCursor *c, int nframes, hipStream_t s)
@@ -229,9 +232,9 @@ int launch_vif_scale(const Geometry *g, const FeatureBuffers *b, int order, int 
     float *nr = sc < 3 ? b->vif_ref[sc + 1] : nullptr, *nd = sc < 3 ? b->vif_dis[sc + 1] : nullptr;
     const size_t nfs = sc < 3 ? (size_t)g->vw[sc + 1] * g->vh[sc + 1] : 0;
     const int nrs = sc < 3 ? g->vw[sc + 1] : 0;
-    HIP_TRY(vk_launch_vif_stat(sc, order, c->ref, c->dis, c->frame_stride, c->row_stride, g->vw[sc], g->vh[sc], nframes,
+    HIP_TRY(vk_launch_vif_stat(sc, order, c->ref, c->dis, c->sample, c->frame_stride, c->row_stride, g->vw[sc], g->vh[sc], nframes,
                                b->partials + g->part_off_vif[sc], nr, nd, nfs, nrs, s));
-    *c = { nr, nd, nfs, nrs };
+    *c = { nr, nd, 4, nfs, nrs };
     return 0;
 }
 
@@ -241,10 +244,10 @@ int launch_adm_scale(const Geometry *g, const FeatureBuffers *b, int order, int 
     const int bw = g->aw[sc + 1], bh = g->ah[sc + 1];
     const size_t lfs = (size_t)bw * bh;
     float *lr = sc < 3 ? b->adm_ref[sc + 1] : nullptr, *ld = sc < 3 ? b->adm_dis[sc + 1] : nullptr;
-    HIP_TRY(vk_launch_adm_scale(sc, order, c->ref, c->dis, c->frame_stride, c->row_stride, g->aw[sc], g->ah[sc], lr, ld, lfs, bw,
+    HIP_TRY(vk_launch_adm_scale(sc, order, c->ref, c->dis, c->sample, c->frame_stride, c->row_stride, g->aw[sc], g->ah[sc], lr, ld, lfs, bw,
                                 g->rfac[2 * sc], g->rfac[2 * sc + 1], g->win[sc][0], g->win[sc][1], g->win[sc][2], g->win[sc][3], nframes,
                                 b->partials + g->part_off_adm[sc], s));
-    *c = { lr, ld, lfs, bw };
+    *c = { lr, ld, 4, lfs, bw };
     return 0;
 }
 
@@ -260,21 +263,40 @@ int fill_reduce_table(const Geometry *g, vk_reduce_table *tab)
     return q;
 }
 
-int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, size_t row_stride_bytes,
+int ensure_stage(vmaf_hip_engine *e, int slot);
+
+// in_ref / in_dis: device planes of `sample` bytes per sample (4 = fp32 as a read_frame callback delivers them, 1 / 2 = raw
+// luma as the YUV file holds it).  The feature kernels read them as they are; only the optional metrics, whose kernels
+// take fp32 planes, get a widened copy of raw input.
+int enqueue_batch(vmaf_hip_engine *e, const void *in_ref, const void *in_dis, int sample, size_t row_stride_bytes,
                   size_t frame_stride_bytes, int nframes, int continue_sequence)
 {
-    if (row_stride_bytes % 4 || frame_stride_bytes % 4) return fail("strides must be multiples of 4 bytes");
-    if (row_stride_bytes < (size_t)e->w * 4) return fail("row stride %zu smaller than a row", row_stride_bytes);
+    if (row_stride_bytes % sample || frame_stride_bytes % sample) return fail("strides must be multiples of the sample size (%d bytes)", sample);
+    if (row_stride_bytes < (size_t)e->w * sample) return fail("row stride %zu smaller than a row", row_stride_bytes);
     if (nframes > 1 && frame_stride_bytes < row_stride_bytes * e->h) return fail("frame stride smaller than a frame");
-    const int rs = (int)(row_stride_bytes / 4);
-    const size_t fs = frame_stride_bytes / 4;
+    if (frame_stride_bytes == 0) frame_stride_bytes = row_stride_bytes * e->h;       // one frame: any stride will do
+    if (row_stride_bytes * e->h > 0xFFFFFFFFu) return fail("one plane must stay below 4 GiB");
+    const int in_rs = (int)(row_stride_bytes / sample);
+    const size_t in_fs = frame_stride_bytes / sample;
     const bool has_carry = continue_sequence && e->carry_valid;
     if (continue_sequence && !e->carry_valid) return fail("continue_sequence set but the engine holds no previous frame");
+    const bool any_metric = e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr;
 
     const int slot = (e->pend_head + e->pend_count) % kDepth;
     e->partials = e->partials_set[slot];
     e->sums_dev = e->sums_set[slot];
     if (e->timed) HIP_TRY(hipEventRecord(e->ev_t0[slot], e->s_main));
+    // fp32 view of the input for the metric kernels (dense planes); the features never use it
+    const float *d_ref = static_cast<const float *>(in_ref), *d_dis = static_cast<const float *>(in_dis);
+    int rs = in_rs;
+    size_t fs = in_fs;
+    if (any_metric && sample != 4) {
+        if (ensure_stage(e, slot)) return 1;
+        HIP_TRY(vk_launch_widen(in_ref, sample, row_stride_bytes, frame_stride_bytes, e->stage_ref[slot], e->w, e->h, nframes, e->s_main));
+        HIP_TRY(vk_launch_widen(in_dis, sample, row_stride_bytes, frame_stride_bytes, e->stage_dis[slot], e->w, e->h, nframes, e->s_main));
+        d_ref = e->stage_ref[slot]; d_dis = e->stage_dis[slot];
+        rs = e->w; fs = (size_t)e->w * e->h;
+    }
     HIP_TRY(hipEventRecord(e->ev_in, e->s_main));             // inputs (staging copies) are ready at this point
     // When the ADM chain and the motion launch start.  In the reference's orders the scale-0 VIF launch saturates the
     // VALUs on its own, so they start after it and share the GPU with VIF scales 1-3, which are too small to fill it
@@ -290,7 +312,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     // ---- optional metrics on their own stream (combo.c:168-230: before the -128 offset, i.e. on the planes as given)
     static const bool psnr_fuse_env = !getenv("VMAF_HIP_PSNR_FUSED") || atoi(getenv("VMAF_HIP_PSNR_FUSED")) != 0;   // 0: A/B measurements
     const bool psnr_fused = psnr_fuse_env && e->m_psnr && e->m_ms;
-    if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) {
+    if (any_metric) {
         hipStream_t q = e->s_iqa;
         HIP_TRY(hipStreamWaitEvent(q, e->ev_in, 0));
         // with MS-SSIM on, its full-resolution launch forms the PSNR noise sums from the samples it stages (one read less)
@@ -323,7 +345,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     }
 
     // ---- VIF chain (vif.c:130-275) on s_main
-    PlaneCursor vc = { d_ref, d_dis, fs, rs };
+    PlaneCursor vc = { in_ref, in_dis, sample, in_fs, in_rs };
     for (int sc = 0; sc < 4; ++sc) {
         if (e->timed && sc == 0) HIP_TRY(hipEventRecord(e->ev_k0[slot], e->s_main));
         if (launch_vif_scale(e, e, e->order, sc, &vc, nframes, e->s_main)) return 1;
@@ -336,13 +358,13 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     }
 
     // ---- ADM chain (adm.c:125-254) on s_adm
-    PlaneCursor ac = { d_ref, d_dis, fs, rs };
+    PlaneCursor ac = { in_ref, in_dis, sample, in_fs, in_rs };
     for (int sc = 0; sc < 4; ++sc)
         if (launch_adm_scale(e, e, e->order, sc, &ac, nframes, e->s_adm)) return 1;
     HIP_TRY(hipEventRecord(e->ev_adm, e->s_adm));
 
     // ---- motion (combo.c:309-326) on s_mot
-    HIP_TRY(vk_launch_motion(e->order, d_ref, 4, fs * 4, rs * 4, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
+    HIP_TRY(vk_launch_motion(e->order, in_ref, sample, frame_stride_bytes, (int)row_stride_bytes, e->w, e->h, nframes, has_carry ? 1 : 0, e->carry[e->carry_cur], e->carry[1 - e->carry_cur],
                              e->partials + e->part_off_mot, e->s_mot));
     HIP_TRY(hipEventRecord(e->ev_mot, e->s_mot));
     e->carry_cur = 1 - e->carry_cur;
@@ -362,7 +384,7 @@ int enqueue_batch(vmaf_hip_engine *e, const float *d_ref, const float *d_dis, si
     }
     HIP_TRY(hipStreamWaitEvent(s_join, e->ev_adm, 0));
     HIP_TRY(hipStreamWaitEvent(s_join, e->ev_mot, 0));
-    if (e->m_psnr || e->m_ssim || e->m_ms || e->m_ansnr) HIP_TRY(hipStreamWaitEvent(s_join, e->ev_iqa, 0));
+    if (any_metric) HIP_TRY(hipStreamWaitEvent(s_join, e->ev_iqa, 0));
     vk_reduce_table tab;
     int q = fill_reduce_table(e, &tab);
     tab.d[q++] = { e->part_off_psnr, e->m_psnr ? (psnr_fused ? e->tiles_ms[0] : e->tiles_psnr) : 0, 1, 0 };
@@ -531,8 +553,6 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
         rc |= alloc_planes(&e->adm_dis[s], B * e->aw[s] * e->ah[s]);
     }
     for (int i = 0; i < 2 && !rc; ++i) rc |= alloc_planes(&e->carry[i], (size_t)width * height);
-    if (!rc) rc |= alloc_planes(&e->stage_ref[0], B * width * height);
-    if (!rc) rc |= alloc_planes(&e->stage_dis[0], B * width * height);
 
     const size_t off = e->part_total;
     for (int i = 0; i < kDepth && !rc; ++i)
@@ -562,6 +582,7 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
         (void)hipFree(e->stage_ref[i]); (void)hipFree(e->stage_dis[i]);
         (void)hipFree(e->raw_ref[i]); (void)hipFree(e->raw_dis[i]);
     }
+    (void)hipFree(e->seed_buf);
     (void)hipFree(e->ssim_ref); (void)hipFree(e->ssim_dis);
     for (int i = 1; i < 5; ++i) { (void)hipFree(e->ms_ref[i]); (void)hipFree(e->ms_dis[i]); }
     if (e->ev_iqa) (void)hipEventDestroy(e->ev_iqa);
@@ -725,7 +746,7 @@ int vmaf_hip_extract_device_async(vmaf_hip_engine *e, const float *d_ref, const 
                                   size_t frame_stride_bytes, int nframes, int continue_sequence, double *atoms_out)
 {
     if (check_call(e, d_ref, d_dis, nframes, atoms_out)) return 1;
-    if (enqueue_batch(e, d_ref, d_dis, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence)) return 1;
+    if (enqueue_batch(e, d_ref, d_dis, 4, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence)) return 1;
     push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
@@ -740,7 +761,6 @@ int vmaf_hip_extract_device(vmaf_hip_engine *e, const float *d_ref, const float 
 
 // The slot the next asynchronous call takes.  Its staging buffers are free: the call that used them last (two calls ago)
 // has been synchronised by the caller, or check_call would have refused this one.
-static int ensure_stage(vmaf_hip_engine *e, int slot);
 static int next_slot(const vmaf_hip_engine *e) { return (e->pend_head + e->pend_count) % kDepth; }
 
 // Called after the H2D copies of a host-pointer call were put on s_copy: the kernels on s_main wait for them, and only
@@ -775,7 +795,7 @@ int vmaf_hip_extract_host_async(vmaf_hip_engine *e, const float *h_ref, const fl
         }
     }
     if (copies_done(e, slot)) return 1;
-    if (enqueue_batch(e, e->stage_ref[slot], e->stage_dis[slot], dense_row, dense_frame, nframes, continue_sequence)) return 1;
+    if (enqueue_batch(e, e->stage_ref[slot], e->stage_dis[slot], 4, dense_row, dense_frame, nframes, continue_sequence)) return 1;
     push_pending(e, nframes, continue_sequence, atoms_out);
     return 0;
 }
@@ -799,28 +819,16 @@ static int check_raw(vmaf_hip_engine *e, int bytes_per_sample, size_t row_stride
     return 0;
 }
 
-// second fp32 staging set, for the call in pending slot 1: only callers that keep two host-pointer or raw calls in flight pay for it
-static int ensure_stage(vmaf_hip_engine *e, int slot)
+// fp32 staging set of a pending slot, allocated on first use: the fp32 host path copies into it, and raw input is widened
+// into it when the optional metrics (whose kernels take fp32 planes) are on
+namespace {
+int ensure_stage(vmaf_hip_engine *e, int slot)
 {
     if (e->stage_ref[slot]) return 0;
     const size_t floats = (size_t)e->max_batch * e->w * e->h;
     return alloc_planes(&e->stage_ref[slot], floats) || alloc_planes(&e->stage_dis[slot], floats);
 }
-
-static int widen_and_enqueue(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bps, size_t rs, size_t fs, int nframes,
-                             int continue_sequence, double *atoms_out)
-{
-    // every call in flight owns the staging set of its pending slot: one rule for the raw and the fp32 host paths, so that
-    // mixing them on one engine stays safe (an fp32 host call copies into its set on s_copy while the previous call runs)
-    const int slot = next_slot(e);
-    if (ensure_stage(e, slot)) return 1;
-    HIP_TRY(vk_launch_widen(d_ref, bps, rs, fs, e->stage_ref[slot], e->w, e->h, nframes, e->s_main));
-    HIP_TRY(vk_launch_widen(d_dis, bps, rs, fs, e->stage_dis[slot], e->w, e->h, nframes, e->s_main));
-    const size_t dense_row = (size_t)e->w * 4, dense_frame = dense_row * e->h;
-    if (enqueue_batch(e, e->stage_ref[slot], e->stage_dis[slot], dense_row, dense_frame, nframes, continue_sequence)) return 1;
-    push_pending(e, nframes, continue_sequence, atoms_out);
-    return 0;
-}
+}  // namespace
 
 int vmaf_hip_extract_device_raw_async(vmaf_hip_engine *e, const void *d_ref, const void *d_dis, int bytes_per_sample,
                                       size_t row_stride_bytes, size_t frame_stride_bytes, int nframes, int continue_sequence,
@@ -828,7 +836,9 @@ int vmaf_hip_extract_device_raw_async(vmaf_hip_engine *e, const void *d_ref, con
 {
     if (check_call(e, d_ref, d_dis, nframes, atoms_out)) return 1;
     if (check_raw(e, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes)) return 1;
-    return widen_and_enqueue(e, d_ref, d_dis, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence, atoms_out);
+    if (enqueue_batch(e, d_ref, d_dis, bytes_per_sample, row_stride_bytes, frame_stride_bytes, nframes, continue_sequence)) return 1;
+    push_pending(e, nframes, continue_sequence, atoms_out);
+    return 0;
 }
 
 int vmaf_hip_extract_host_raw_async(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample,
@@ -855,7 +865,9 @@ int vmaf_hip_extract_host_raw_async(vmaf_hip_engine *e, const void *h_ref, const
         }
     }
     if (copies_done(e, slot)) return 1;
-    return widen_and_enqueue(e, e->raw_ref[slot], e->raw_dis[slot], bytes_per_sample, dense_row, dense_frame, nframes, continue_sequence, atoms_out);
+    if (enqueue_batch(e, e->raw_ref[slot], e->raw_dis[slot], bytes_per_sample, dense_row, dense_frame, nframes, continue_sequence)) return 1;
+    push_pending(e, nframes, continue_sequence, atoms_out);
+    return 0;
 }
 
 int vmaf_hip_extract_host_raw(vmaf_hip_engine *e, const void *h_ref, const void *h_dis, int bytes_per_sample, size_t row_stride_bytes,
@@ -876,18 +888,34 @@ int vmaf_hip_extract_device_raw(vmaf_hip_engine *e, const void *d_ref, const voi
     return vmaf_hip_engine_sync(e);
 }
 
+// One-frame motion launch without predecessor: only its carry_out side effect is used (the blurred plane the next
+// extract call with continue_sequence = 1 compares its first frame with).
+static int motion_seed(vmaf_hip_engine *e, const void *d_ref, int sample, size_t row_stride_bytes)
+{
+    HIP_TRY(vk_launch_motion(e->order, d_ref, sample, 0, (int)row_stride_bytes, e->w, e->h, 1, 0, e->carry[e->carry_cur],
+                             e->carry[1 - e->carry_cur], e->partials + e->part_off_mot, e->s_main));
+    e->carry_cur = 1 - e->carry_cur;
+    e->carry_valid = true;
+    HIP_TRY(hipStreamSynchronize(e->s_main));
+    return 0;
+}
+
+// a host frame lands in a one-plane device buffer (allocated on first use) and is blurred from there
+static int motion_seed_from_host(vmaf_hip_engine *e, const void *h_ref, int sample, size_t row_stride_bytes)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->seed_buf && hipMalloc(&e->seed_buf, (size_t)e->w * e->h * 4) != hipSuccess) return fail("hipMalloc(motion seed plane) failed");
+    const size_t dense_row = (size_t)e->w * sample;
+    HIP_TRY(hipMemcpy2DAsync(e->seed_buf, dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
+    return motion_seed(e, e->seed_buf, sample, dense_row);
+}
+
 int vmaf_hip_motion_seed_host_raw(vmaf_hip_engine *e, const void *h_ref, int bytes_per_sample, size_t row_stride_bytes)
 {
     if (!e || !h_ref) return fail("null argument");
     if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (check_raw(e, bytes_per_sample, row_stride_bytes, 0, 1)) return 1;
-    HIP_TRY(hipSetDevice(e->device));
-    // the float staging plane doubles as the landing area of the raw rows (its tail) - one frame only
-    const size_t dense_row = (size_t)e->w * bytes_per_sample;
-    unsigned char *tmp = (unsigned char *)(e->stage_dis[0]);
-    HIP_TRY(hipMemcpy2DAsync(tmp, dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
-    HIP_TRY(vk_launch_widen(tmp, bytes_per_sample, dense_row, dense_row * e->h, e->stage_ref[0], e->w, e->h, 1, e->s_main));
-    return vmaf_hip_motion_seed_device(e, e->stage_ref[0], (size_t)e->w * 4);
+    return motion_seed_from_host(e, h_ref, bytes_per_sample, row_stride_bytes);
 }
 
 void *vmaf_hip_host_alloc(size_t bytes)
@@ -905,24 +933,24 @@ int vmaf_hip_motion_seed_device(vmaf_hip_engine *e, const float *d_ref, size_t r
     if (e->pend_count) return fail("a previous async extract has not been synchronised");
     if (row_stride_bytes % 4 || row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
     HIP_TRY(hipSetDevice(e->device));
-    // one-frame motion launch without predecessor: only its carry_out side effect is used
-    HIP_TRY(vk_launch_motion(e->order, d_ref, 4, 0, (int)row_stride_bytes, e->w, e->h, 1, 0, e->carry[e->carry_cur],
-                             e->carry[1 - e->carry_cur], e->partials + e->part_off_mot, e->s_main));
-    e->carry_cur = 1 - e->carry_cur;
-    e->carry_valid = true;
-    HIP_TRY(hipStreamSynchronize(e->s_main));
-    return 0;
+    return motion_seed(e, d_ref, 4, row_stride_bytes);
+}
+
+int vmaf_hip_motion_seed_device_raw(vmaf_hip_engine *e, const void *d_ref, int bytes_per_sample, size_t row_stride_bytes)
+{
+    if (!e || !d_ref) return fail("null argument");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
+    if (check_raw(e, bytes_per_sample, row_stride_bytes, 0, 1)) return 1;
+    HIP_TRY(hipSetDevice(e->device));
+    return motion_seed(e, d_ref, bytes_per_sample, row_stride_bytes);
 }
 
 int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row_stride_bytes)
 {
     if (!e || !h_ref) return fail("null argument");
     if (row_stride_bytes < (size_t)e->w * 4) return fail("bad row stride %zu", row_stride_bytes);
-    HIP_TRY(hipSetDevice(e->device));
-    const size_t dense_row = (size_t)e->w * 4;
     if (e->pend_count) return fail("a previous async extract has not been synchronised");
-    HIP_TRY(hipMemcpy2DAsync(e->stage_ref[0], dense_row, h_ref, row_stride_bytes, dense_row, e->h, hipMemcpyHostToDevice, e->s_main));
-    return vmaf_hip_motion_seed_device(e, e->stage_ref[0], dense_row);
+    return motion_seed_from_host(e, h_ref, 4, row_stride_bytes);
 }
 
 int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho,
@@ -991,10 +1019,10 @@ int vmaf_hip_extract_device_noalloc(int device, void *stream, const float *d_ref
     // the engine's launches, one after the other on the caller's stream.  Nothing in the scratch area has to start at
     // zero: every workgroup stores its partial sums, reduce_kernel stores every sum, and the pyramid planes are written
     // before they are read - the previous call's contents are simply overwritten.
-    PlaneCursor vc = { d_ref, d_dis, fs, rs };
+    PlaneCursor vc = { d_ref, d_dis, 4, fs, rs };
     for (int sc = 0; sc < 4; ++sc)
         if (launch_vif_scale(&g, &L.b, conv_order, sc, &vc, nframes, s)) return 1;
-    PlaneCursor ac = { d_ref, d_dis, fs, rs };
+    PlaneCursor ac = { d_ref, d_dis, 4, fs, rs };
     for (int sc = 0; sc < 4; ++sc)
         if (launch_adm_scale(&g, &L.b, conv_order, sc, &ac, nframes, s)) return 1;
     HIP_TRY(vk_launch_motion(conv_order, d_ref, 4, fs * 4, rs * 4, width, height, nframes, 0, L.carry, L.carry, L.b.partials + g.part_off_mot, s));

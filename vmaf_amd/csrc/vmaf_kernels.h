@@ -33,12 +33,13 @@ int vk_vif_tiles(int w, int h);
 int vk_adm_tiles(int w, int h);     // w,h = INPUT size of the scale
 int vk_motion_tiles(int w, int h);
 
-// order: 0 = the reference's scalar tap order (disable_avx), 1 = its AVX order (default on x86; two launches:
-// interior tiles, then the border-frame tiles with per-sample order - same partial slots)
-hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
+// order: 0 = the reference's scalar tap order (disable_avx), 1 = its AVX order (default on x86), 2 = fused multiply-adds.
+// ref / dis at scale 0: the caller's picture, sample_bytes 4 = fp32 planes, 1 = 8-bit samples, 2 = little-endian 16-bit words
+// (value / 4.0), widened in the kernels' loads (file_io.c:112-116,159-163); strides in samples.  Scales 1-3: fp32 only.
+hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s);
-hipError_t vk_launch_adm_scale(int scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+hipError_t vk_launch_adm_scale(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
                                double *partial, hipStream_t s);

@@ -331,8 +331,10 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
     }
 }
 
-#define VIF_KERNEL_PARAMS const float *__restrict__ ref, const float *__restrict__ dis, size_t frame_stride, int row_stride, int w, int h, \
-                          double *__restrict__ partial, float *__restrict__ oref, float *__restrict__ odis,                          \
+// T = sample type of the input planes (strides in samples): float for the pyramid levels and fp32 pictures, unsigned char /
+// unsigned short for raw luma at scale 0 (widened in the loads, load_px)
+#define VIF_KERNEL_PARAMS const T *__restrict__ ref, const T *__restrict__ dis, size_t frame_stride, int row_stride, int w, int h, \
+                          double *__restrict__ partial, float *__restrict__ oref, float *__restrict__ odis,                  \
                           size_t out_frame_stride, int out_row_stride
 #define VIF_KERNEL_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
 
@@ -385,8 +387,8 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int FW, bool OFFSET, int ORDER, bool BORDER>
-__device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile_id, const float *__restrict__ ref, const float *__restrict__ dis,
+template <int FW, bool OFFSET, int ORDER, bool BORDER, typename T>
+__device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile_id, const T *__restrict__ ref, const T *__restrict__ dis,
                                               size_t frame_stride, int row_stride, int w, int h,
                                               double *__restrict__ partial,
                                               float *__restrict__ oref, float *__restrict__ odis,
@@ -406,21 +408,21 @@ __device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile
     double acc[2] = { 0.0, 0.0 };
 
     if (y0 < h) {
-        const float *fr = ref + (size_t)blockIdx.z * frame_stride;
-        const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+        const T *fr = ref + (size_t)blockIdx.z * frame_stride;
+        const T *fd = dis + (size_t)blockIdx.z * frame_stride;
         // ---- vertical pass: lane = column x0 - R + lane
         float vo[5][VWV_TH];
         const int vc = lane;
         const int gxc = mirror_idx(x0 - R + vc, w);
         {
             float rv[NW], dv[NW], t[NW];
-            const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
-            const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
+            const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * (unsigned)sizeof(T);
+            const auto br = sample_rsrc(fr, frame_bytes), bd = sample_rsrc(fd, frame_bytes);
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                const int roff = mirror_idx(y0 - R + i, h) * row_stride * 4;       // wave-uniform: SGPR
-                rv[i] = buf_load(br, gxc * 4, roff);
-                dv[i] = buf_load(bd, gxc * 4, roff);
+                const int roff = mirror_idx(y0 - R + i, h) * row_stride * (int)sizeof(T);   // wave-uniform: SGPR
+                rv[i] = load_px<T>(br, gxc, roff);
+                dv[i] = load_px<T>(bd, gxc, roff);
             }
             if (OFFSET) {
 #pragma unroll
@@ -535,15 +537,15 @@ __device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
 }
 
-template <int FW, bool OFFSET, int ORDER>
+template <int FW, bool OFFSET, int ORDER, typename T>
 __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_kernel(VIF_KERNEL_PARAMS)
 {
     __shared__ __attribute__((aligned(16))) float smem[(VIF_THREADS / 64) * VifWaveGeom<FW>::WAVE_FLOATS];
     __shared__ double red[2 * (VIF_THREADS / 64)];
-    vif_wave_tile<FW, OFFSET, ORDER, false>(smem, red, xcd_tile_index(), VIF_KERNEL_ARGS);
+    vif_wave_tile<FW, OFFSET, ORDER, false, T>(smem, red, xcd_tile_index(), VIF_KERNEL_ARGS);
 }
 
-template <int FW, bool OFFSET>
+template <int FW, bool OFFSET, typename T>
 __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_kernel(VIF_KERNEL_PARAMS, int nb_pad)
 {
     __shared__ __attribute__((aligned(16))) float smem[(VIF_THREADS / 64) * VifWaveGeom<FW>::WAVE_FLOATS];
@@ -555,10 +557,10 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_avx_
         if (b >= bg.ntiles) return;                           // padding workgroup
         int tx, ty;
         border_tile_at(bg, b, tx, ty);
-        vif_wave_tile<FW, OFFSET, ORDER_AVX, true>(smem, red, ty * ntx + tx, VIF_KERNEL_ARGS);
+        vif_wave_tile<FW, OFFSET, ORDER_AVX, true, T>(smem, red, ty * ntx + tx, VIF_KERNEL_ARGS);
     } else {
         const int i = xcd_tile_index(b - nb_pad, (int)gridDim.x - nb_pad), iw = bg.tx_r - 1;
-        vif_wave_tile<FW, OFFSET, ORDER_AVX, false>(smem, red, (1 + i / iw) * ntx + 1 + i % iw, VIF_KERNEL_ARGS);
+        vif_wave_tile<FW, OFFSET, ORDER_AVX, false, T>(smem, red, (1 + i / iw) * ntx + 1 + i % iw, VIF_KERNEL_ARGS);
     }
 }
 
@@ -606,7 +608,7 @@ __device__ __forceinline__ void vwg_item(int tid, int &row, int &strip)
     }
 }
 
-template <int FW, bool OFFSET, int ORDER>
+template <int FW, bool OFFSET, int ORDER, typename T>
 __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_kernel(VIF_KERNEL_PARAMS)
 {
     using G = VifWgGeom<FW>;
@@ -624,8 +626,8 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
     const int x0 = tx * VWG_TW, y0 = (tile_id / ntx) * VWG_TH;
     // the last tile of a row may be narrower (w % 8 == 0: a whole number of strips); waves and threads beyond it idle
     const int tw = min(VWG_TW, w - x0), nstrips = tw / VWG_HS;
-    const float *fr = ref + (size_t)blockIdx.z * frame_stride;
-    const float *fd = dis + (size_t)blockIdx.z * frame_stride;
+    const T *fr = ref + (size_t)blockIdx.z * frame_stride;
+    const T *fd = dis + (size_t)blockIdx.z * frame_stride;
     double acc[2] = { 0.0, 0.0 };
 
     // ---- vertical pass: thread = column x0 - R + tid
@@ -635,13 +637,13 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
     const int gxc = mirror_idx(x0 - R + vc, w);
     if (wv * 64 < tw + 2 * R) {                                // wave-uniform: a wave without columns skips the pass
         float rv[NW], dv[NW], t[NW];
-        const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * 4u;
-        const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
+        const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride * (unsigned)sizeof(T);
+        const auto br = sample_rsrc(fr, frame_bytes), bd = sample_rsrc(fd, frame_bytes);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int roff = mirror_idx(y0 - R + i, h) * row_stride * 4;           // workgroup-uniform: SGPR
-            rv[i] = buf_load(br, gxc * 4, roff);
-            dv[i] = buf_load(bd, gxc * 4, roff);
+            const int roff = mirror_idx(y0 - R + i, h) * row_stride * (int)sizeof(T);   // workgroup-uniform: SGPR
+            rv[i] = load_px<T>(br, gxc, roff);
+            dv[i] = load_px<T>(bd, gxc, roff);
         }
         if (OFFSET) {
 #pragma unroll
@@ -812,8 +814,8 @@ static_assert(ADM_COLS == 128 && ADM_THREADS == 2 * ADM_COLS, "phase 1 maps thre
 // FAST (ORDER_FMA, opt-in): the 4-tap db2 sums with fused multiply-adds; everything after the DWT is unchanged.
 template <bool FAST> __device__ __forceinline__ float db2_acc(float acc, float c, float x) { return FAST ? __builtin_fmaf(c, x, acc) : acc + c * x; }
 
-template <bool OFFSET, bool FAST>
-__global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
+template <bool OFFSET, bool FAST, typename T>
+__global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__restrict__ ref, const T *__restrict__ dis,
                                                                    size_t in_frame_stride, int in_row_stride, int w, int h,
                                                                    float *__restrict__ ll_ref, float *__restrict__ ll_dis,
                                                                    size_t ll_frame_stride, int ll_row_stride,
@@ -875,8 +877,8 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
     }
 #endif
     const int cx0 = (tile_id % ntx) * ADM_TW, cy0 = (tile_id / ntx) * ADM_TH;   // first interior coefficient
-    const float *fr = ref + (size_t)blockIdx.z * in_frame_stride;
-    const float *fd = dis + (size_t)blockIdx.z * in_frame_stride;
+    const T *fr = ref + (size_t)blockIdx.z * in_frame_stride;
+    const T *fd = dis + (size_t)blockIdx.z * in_frame_stride;
     // The six sums only look at the centre window [left, right) x [top, bottom) (adm_sum_cube, adm_tools.c:55-60), and a
     // coefficient's masked value depends on its 3x3 neighbourhood only, which every workgroup computes for itself.  A
     // workgroup whose interior coefficients all lie outside the window (28 % of them at 1080p) therefore contributes
@@ -893,13 +895,13 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const float *
         const int ty0 = half * ADM_RPT;
         const int iy0 = 2 * (cy0 - 1 + ty0) - 1;
         float pr[2 * ADM_RPT + 2], pd[2 * ADM_RPT + 2];
-        const unsigned frame_bytes = (unsigned)h * (unsigned)in_row_stride * 4u;
-        const auto br = frame_rsrc(fr, frame_bytes), bd = frame_rsrc(fd, frame_bytes);
+        const unsigned frame_bytes = (unsigned)h * (unsigned)in_row_stride * (unsigned)sizeof(T);
+        const auto br = sample_rsrc(fr, frame_bytes), bd = sample_rsrc(fd, frame_bytes);
 #pragma unroll
         for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
-            const int roff = mirror_idx(iy0 + k, h) * in_row_stride * 4;   // wave-uniform: SGPR
-            pr[k] = buf_load(br, xc * 4, roff);
-            pd[k] = buf_load(bd, xc * 4, roff);
+            const int roff = mirror_idx(iy0 + k, h) * in_row_stride * (int)sizeof(T);   // wave-uniform: SGPR
+            pr[k] = load_px<T>(br, xc, roff);
+            pd[k] = load_px<T>(bd, xc, roff);
         }
         if (OFFSET) {
 #pragma unroll
@@ -1842,52 +1844,67 @@ int vk_adm_tiles(int w, int h)
 // doubles per frame in the partial buffer: [0] the frame's SAD total (fp32 value), then its h row sums as packed floats
 int vk_motion_tiles(int w, int h) { (void)w; return 1 + (h + 1) / 2; }
 
-hipError_t vk_launch_vif_stat(int scale, int order, const float *ref, const float *dis, size_t frame_stride, int row_stride,
+hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s)
 {
     static const int fw[4] = { 17, 9, 5, 3 };
+    if (sample_bytes != 4 && scale != 0) return hipErrorInvalidValue;      // only the picture itself can be raw luma
     const dim3 g = grid_flat(w, h, VIF_TW, VIF_TH, nframes);
     const BorderGeom bg = border_geom(w, h, fw[scale] / 2, VIF_TW, VIF_TH);
     const int nb = bg.ntiles, ni = (bg.tx_r - 1) * (bg.ty_b - 1), nb_pad = ni > 0 ? (nb + 7) / 8 * 8 : nb;
     const dim3 gm(nb_pad + ni, 1, nframes);                   // border-frame tiles (padded) first, then the interior rectangle
-#define VIF_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+#define VIF_ARGS (const T *)ref, (const T *)dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
     const bool wg = vif_use_wg(w, h);
     const dim3 gw(wg ? vk_vif_tiles(w, h) : 1, 1, nframes);
-#define VIF_STAT(FW, OFF)                                                                              \
-    if (wg) {                                                                                          \
-        if (order == ORDER_SCALAR) vif_stat_wg_kernel<FW, OFF, ORDER_SCALAR><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
-        else if (order == ORDER_FMA) vif_stat_wg_kernel<FW, OFF, ORDER_FMA><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
-        else vif_stat_wg_kernel<FW, OFF, ORDER_AVX><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);              \
-    } else if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
-    else if (order == ORDER_FMA) vif_stat_kernel<FW, OFF, ORDER_FMA><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
-    else vif_stat_avx_kernel<FW, OFF><<<gm, VIF_THREADS, 0, s>>>(VIF_ARGS, nb_pad)
+#define VIF_STAT(FW, OFF, TYPE)                                                                        \
+    do {                                                                                               \
+        using T = TYPE;                                                                                \
+        if (wg) {                                                                                      \
+            if (order == ORDER_SCALAR) vif_stat_wg_kernel<FW, OFF, ORDER_SCALAR, T><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
+            else if (order == ORDER_FMA) vif_stat_wg_kernel<FW, OFF, ORDER_FMA, T><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
+            else vif_stat_wg_kernel<FW, OFF, ORDER_AVX, T><<<gw, VIF_THREADS, 0, s>>>(VIF_ARGS);       \
+        } else if (order == ORDER_SCALAR) vif_stat_kernel<FW, OFF, ORDER_SCALAR, T><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);   \
+        else if (order == ORDER_FMA) vif_stat_kernel<FW, OFF, ORDER_FMA, T><<<g, VIF_THREADS, 0, s>>>(VIF_ARGS);    \
+        else vif_stat_avx_kernel<FW, OFF, T><<<gm, VIF_THREADS, 0, s>>>(VIF_ARGS, nb_pad);             \
+    } while (0)
     switch (scale) {
-    case 0: VIF_STAT(17, true); break;
-    case 1: VIF_STAT(9, false); break;
-    case 2: VIF_STAT(5, false); break;
-    default: VIF_STAT(3, false); break;
+    case 0:
+        if (sample_bytes == 4) VIF_STAT(17, true, float);
+        else if (sample_bytes == 1) VIF_STAT(17, true, unsigned char);
+        else if (sample_bytes == 2) VIF_STAT(17, true, unsigned short);
+        else return hipErrorInvalidValue;
+        break;
+    case 1: VIF_STAT(9, false, float); break;
+    case 2: VIF_STAT(5, false, float); break;
+    default: VIF_STAT(3, false, float); break;
     }
 #undef VIF_STAT
 #undef VIF_ARGS
     return hipGetLastError();
 }
 
-hipError_t vk_launch_adm_scale(int scale, int order, const float *ref, const float *dis, size_t in_frame_stride, int in_row_stride,
+hipError_t vk_launch_adm_scale(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,
                                double *partial, hipStream_t s)
 {
     const int bw = (w + 1) / 2, bh = (h + 1) / 2;
     const dim3 g = grid_flat(bw, bh, ADM_TW, ADM_TH, nframes);
-#define ADM_ARGS ref, dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride, ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial
-    if (order == ORDER_FMA) {
-        if (scale == 0) adm_scale_kernel<true, true><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
-        else adm_scale_kernel<false, true><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
-    } else {
-        if (scale == 0) adm_scale_kernel<true, false><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
-        else adm_scale_kernel<false, false><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);
-    }
+    if (sample_bytes != 4 && scale != 0) return hipErrorInvalidValue;
+#define ADM_ARGS (const T *)ref, (const T *)dis, in_frame_stride, in_row_stride, w, h, ll_ref, ll_dis, ll_frame_stride, ll_row_stride, rfac_hv, rfac_d, left, top, right, bottom, partial
+#define ADM_SCALE(OFF, TYPE)                                                                                   \
+    do {                                                                                                       \
+        using T = TYPE;                                                                                        \
+        if (order == ORDER_FMA) adm_scale_kernel<OFF, true, T><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);            \
+        else adm_scale_kernel<OFF, false, T><<<g, ADM_THREADS, 0, s>>>(ADM_ARGS);                              \
+    } while (0)
+    if (scale != 0) ADM_SCALE(false, float);
+    else if (sample_bytes == 4) ADM_SCALE(true, float);
+    else if (sample_bytes == 1) ADM_SCALE(true, unsigned char);
+    else if (sample_bytes == 2) ADM_SCALE(true, unsigned short);
+    else return hipErrorInvalidValue;
+#undef ADM_SCALE
 #undef ADM_ARGS
     return hipGetLastError();
 }
