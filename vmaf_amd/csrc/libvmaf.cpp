@@ -18,6 +18,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <atomic>
+
+#include <sched.h>
 
 #include "../../include/libvmaf.h"
 #include "../../include/vmaf_hip.h"
@@ -198,7 +201,7 @@ public:
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
-    // calls fn(i) for i in [0, n) on the helpers and the calling thread; returns the first non-zero result (0 = all fine)
+    // calls fn(i) for i in [0, n) on the helpers and the calling thread; 0 = all fine, else see worse()
     int run(int n, const std::function<int(int)> &fn)
     {
         const int parts = (int)th_.size() + 1;
@@ -212,7 +215,13 @@ public:
         for (int i = 0; i < n; i += parts) if (int r = fn(i)) { rc = r; break; }
         std::unique_lock<std::mutex> l(m_);
         done_.wait(l, [this] { return left_ == 0; });
-        return rc ? rc : rc_;
+        return worse(rc, rc_);
+    }
+    // of two results the one to report: the smallest positive one (fn returns index + 1 of a failed item), else any non-zero
+    static int worse(int a, int b)
+    {
+        if (a > 0 && b > 0) return std::min(a, b);
+        return a > 0 ? a : b > 0 ? b : a ? a : b;
     }
 
 private:
@@ -233,7 +242,7 @@ private:
             int rc = 0;
             for (int i = me; i < n; i += parts) if ((rc = (*fn)(i)) != 0) break;
             std::lock_guard<std::mutex> l(m_);
-            if (rc && !rc_) rc_ = rc;
+            rc_ = worse(rc_, rc);
             if (--left_ == 0) done_.notify_all();
         }
     }
@@ -246,14 +255,20 @@ private:
     bool stop_ = false;
 };
 
-// reader threads per shard: VMAF_HIP_READ_THREADS (default 8; vmafossexec's knob) split over the shards
+// Reader threads PER SHARD: VMAF_HIP_READ_THREADS, default 8 (never fewer than 4 because several shards share the host:
+// one copying thread moves ~8 GB/s out of the page cache, a shard's PCIe link ~51 GB/s - a shard with one or two readers
+// would run at a fraction of its GPU's rate, and eight such shards together at about the rate of ONE well-fed GPU).
+// Bounded by the CPUs this process may run on (sched_getaffinity; hardware_concurrency counts the whole machine).
 int fetch_threads(int shards)
 {
     const char *env = std::getenv("VMAF_HIP_READ_THREADS");
-    int n = env ? std::atoi(env) : 8;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && n > hw) n = hw;
-    return std::max(1, n / std::max(1, shards));
+    if (env && std::atoi(env) > 0) return std::min(std::atoi(env), 64);
+    int cpus = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+    if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
+    int n = cpus > 0 ? cpus / std::max(1, shards) : 8;
+    return std::max(4, std::min(8, n));
 }
 
 int batch_frames(size_t plane)
@@ -264,25 +279,46 @@ int batch_frames(size_t plane)
     return batch;
 }
 
+// What the shards of one video share: the first failure (the one with the lowest frame index wins) and the flag that makes
+// every other shard and reader thread stop at its next frame instead of scoring its whole range first.
+struct ShardAbort {
+    std::atomic<bool> stop{false};
+    std::mutex m;
+    long frame = -1;                                               // lowest failing frame index (-1: a failure without one)
+    std::string msg;
+    void fail(long at, const std::string &what)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (msg.empty() || (at >= 0 && (frame < 0 || at < frame))) { frame = at; msg = what; }
+        stop.store(true);
+    }
+};
+
+// a failure of one shard: the frame it belongs to (-1 = none) and the message
+struct ShardFailure { long frame; std::string msg; };
+
 // One contiguous frame range [start, stop) of a seekable source on one engine: the shard
-// reads and blurs ref frame start-1 itself (motion halo: ref only, no VIF/ADM), then walks its range in double-buffered
-// batches - the reads of batch k+1 overlap the copies and kernels of batch k.  Writes atoms[start..stop).
+// reads and blurs ref frame start-1 itself (motion halo: ref only, no VIF/ADM), then walks its range in batches through a
+// ring of kRing page-locked buffer sets: a READER stage (one thread + the helper threads of FrameFetchers) fills free sets
+// ahead of the GPU, this thread hands ready sets to the engine (at most two calls in flight) and frees a set when its
+// call has been collected - reading, the H2D copies and the kernels of different batches all overlap, and this thread's
+// enqueue time (~0.5 ms per batch) no longer adds to the reading time.  Writes atoms[start..stop).
+// Start-up order: the page-locked buffers first (that initialises the HIP runtime), then the engine is created on a helper
+// thread (device context, streams: ~18 ms) WHILE the reader stage already fetches the first batches.
+constexpr int kRing = 4;
+
 void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar_order, const MetricFlags &mf, long start, long stop,
-                   int readers, double *atoms, double *metrics)
+                   int readers, double *atoms, double *metrics, ShardAbort &abort)
 {
     const size_t stride = (size_t)w * src.bps, plane = stride * h;
-    const int batch = batch_frames(plane);
+    // ~16 MB of luma per plane and batch (8 frames of 8-bit 1080p): with kRing sets that is the page-locked memory two sets
+    // of 32 MB took, and the link is what bounds the run either way (tools/trace_run.sh, VMAF_HIP_BATCH=8 / 16)
+    const int batch = (int)std::min<long>(batch_frames(plane * 2), stop - start);
+    const long nb = (stop - start + batch - 1) / batch;
+    const int ring = (int)std::min<long>(kRing, nb);
     EngineGuard guard;
-    vmaf_hip_engine *e = nullptr;
-    trace("shard: engine create");
-    if (vmaf_hip_engine_create(&e, device, w, h, batch)) throw VmafException(vmaf_hip_last_error());
-    trace("shard: engine created");
-    guard.engines.push_back(e);
-    static const bool fast = std::getenv("VMAF_HIP_FAST") && std::atoi(std::getenv("VMAF_HIP_FAST")) != 0;
-    if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1)) throw VmafException(vmaf_hip_last_error());
-    if (mf.any() && vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit)) throw VmafException(vmaf_hip_last_error());
-    char *ref[2], *dis[2];
-    for (int b = 0; b < 2; ++b) {
+    char *ref[kRing] = {}, *dis[kRing] = {};
+    for (int b = 0; b < ring; ++b) {
         char **pp[2] = { &ref[b], &dis[b] };
         for (auto p : pp) {
             *p = (char *)vmaf_hip_host_alloc(plane * batch);
@@ -291,47 +327,128 @@ void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar
         }
     }
     trace("shard: page-locked buffers ready");
-    FrameFetchers fetch(readers - 1);
-    auto read = [&](char *r, char *d, long frame) {
-        const int ret = src.read_raw_at(r, d, (int)stride, frame, src.user);
-        if (ret) throw VmafException("read_frame failed at frame " + std::to_string(frame) + ".");
-    };
-    if (start > 0) {
-        read(ref[0], dis[0], start - 1);
-        if (vmaf_hip_motion_seed_host_raw(e, ref[0], src.bps, stride)) throw VmafException(vmaf_hip_last_error());
-    }
+    vmaf_hip_engine *e = nullptr;
+    std::string create_err;
+    std::thread creator([&] {
+        if (vmaf_hip_engine_create(&e, device, w, h, batch)) { create_err = vmaf_hip_last_error(); return; }
+        static const bool fast = std::getenv("VMAF_HIP_FAST") && std::atoi(std::getenv("VMAF_HIP_FAST")) != 0;
+        if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1) ||
+            (mf.any() && vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit)))
+            create_err = vmaf_hip_last_error();
+    });
+
+    // ---- reader stage
+    struct Ring {
+        std::mutex m;
+        std::condition_variable cv;
+        bool ready[kRing] = {};                                    // set filled, not yet handed to the engine / collected
+        bool quit = false, failed = false;
+        ShardFailure failure{ -1, "" };
+    } rs;
+    char msg[160];
+    std::snprintf(msg, sizeof msg, "shard: frames [%ld, %ld), %d reader threads, %ld batches of %d, ring of %d", start, stop, readers, nb, batch, ring);
+    trace(msg);
+    std::vector<char> halo;                                        // the halo frame has a buffer of its own
+    std::thread reader([&] {
+        FrameFetchers fetch(readers - 1);
+        auto give_up = [&](long frame, const std::string &what) {
+            std::lock_guard<std::mutex> l(rs.m);
+            rs.failed = true; rs.failure = ShardFailure{ frame, what };
+            rs.cv.notify_all();
+        };
+        if (start > 0) {
+            halo.resize(plane * 2);
+            if (src.read_raw_at(halo.data(), halo.data() + plane, (int)stride, start - 1, src.user))
+                return give_up(start - 1, "read_frame failed at frame " + std::to_string(start - 1) + ".");
+        }
+        for (long k = 0; k < nb; ++k) {
+            const int b = (int)(k % ring);
+            {
+                std::unique_lock<std::mutex> l(rs.m);
+                rs.cv.wait(l, [&] { return !rs.ready[b] || rs.quit; });
+                if (rs.quit) return;
+            }
+            const long at = start + k * batch;
+            const int n = (int)std::min<long>(batch, stop - at);
+            char *rb = ref[b], *db = dis[b];
+            const int bad = fetch.run(n, [&](int i) {
+                if (abort.stop.load(std::memory_order_relaxed)) return -1;
+                return src.read_raw_at(rb + plane * i, db + plane * i, (int)stride, at + i, src.user) ? i + 1 : 0;
+            });
+            if (bad > 0) return give_up(at + bad - 1, "read_frame failed at frame " + std::to_string(at + bad - 1) + ".");
+            if (bad < 0) return give_up(-1, "stopped: another shard failed");
+            std::lock_guard<std::mutex> l(rs.m);
+            rs.ready[b] = true;
+            rs.cv.notify_all();
+        }
+    });
+    // whatever happens below: both helper threads are joined, and the engine the creator made is destroyed with the guard
+    struct Joiner {
+        std::thread &creator, &reader; vmaf_hip_engine *&e; EngineGuard &g; Ring &rs; bool created = false;
+        void join_creator() { if (!created) { creator.join(); if (e) g.engines.push_back(e); created = true; } }
+        ~Joiner()
+        {
+            { std::lock_guard<std::mutex> l(rs.m); rs.quit = true; }
+            rs.cv.notify_all();
+            reader.join();
+            join_creator();
+        }
+    } joiner{creator, reader, e, guard, rs};
+
+    joiner.join_creator();
+    if (!create_err.empty()) throw VmafException(create_err);
+    trace("shard: engine created");
+
     std::vector<double> out[2];
     out[0].resize((size_t)batch * kAtoms); out[1].resize((size_t)batch * kAtoms);
-    struct Pend { long at = 0; int n = 0; } pend[2];
-    int inflight = 0, fill = 0;
-    auto collect = [&]() {                                         // oldest call in flight -> atoms / metrics rows
-        const int b = (fill + 2 - inflight) % 2;
+    struct Pend { long at = 0; int n = 0, set = 0; } pend[2];
+    int inflight = 0, slot = 0;                                    // slot: which of out[] / pend[] the next call takes
+    auto collect = [&]() {                                         // oldest call in flight -> atoms / metrics rows; its buffer set is free
+        const int o = (slot + 2 - inflight) % 2;
         if (vmaf_hip_engine_sync_oldest(e)) throw VmafException(vmaf_hip_last_error());
-        std::copy(out[b].begin(), out[b].begin() + (size_t)pend[b].n * kAtoms, atoms + (size_t)pend[b].at * kAtoms);
-        if (mf.any() && vmaf_hip_engine_get_metrics(e, metrics + (size_t)pend[b].at * VMAF_HIP_METRICS, pend[b].n))
+        std::copy(out[o].begin(), out[o].begin() + (size_t)pend[o].n * kAtoms, atoms + (size_t)pend[o].at * kAtoms);
+        if (mf.any() && vmaf_hip_engine_get_metrics(e, metrics + (size_t)pend[o].at * VMAF_HIP_METRICS, pend[o].n))
             throw VmafException(vmaf_hip_last_error());
         --inflight;
+        { std::lock_guard<std::mutex> l(rs.m); rs.ready[pend[o].set] = false; }
+        rs.cv.notify_all();
     };
-    for (long at = start; at < stop; at += batch) {
+    double t_gpu = 0, t_read = 0, t_enq = 0;                       // VMAF_HIP_TRACE: what this thread waits for
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    for (long k = 0; k < nb; ++k) {
+        if (abort.stop.load(std::memory_order_relaxed)) throw ShardFailure{ -1, "stopped: another shard failed" };
+        const int b = (int)(k % ring);
+        const long at = start + k * batch;
         const int n = (int)std::min<long>(batch, stop - at);
-        if (inflight == 2) collect();                              // frees buffer `fill`
-        char *rb = ref[fill], *db = dis[fill];
-        const int bad = fetch.run(n, [&](int i) { return src.read_raw_at(rb + plane * i, db + plane * i, (int)stride, at + i, src.user) ? i + 1 : 0; });
-        if (bad) throw VmafException("read_frame failed at frame " + std::to_string(at + bad - 1) + ".");
-        if (vmaf_hip_extract_host_raw_async(e, ref[fill], dis[fill], src.bps, stride, plane, n, at > 0 ? 1 : 0, out[fill].data()))
+        const auto t0 = now();
+        if (inflight == 2) collect();
+        const auto t1 = now();
+        {
+            std::unique_lock<std::mutex> l(rs.m);
+            rs.cv.wait(l, [&] { return rs.ready[b] || rs.failed; });
+            if (rs.failed) throw rs.failure;
+        }
+        const auto t2 = now();
+        if (k == 0 && start > 0 && vmaf_hip_motion_seed_host_raw(e, halo.data(), src.bps, stride)) throw VmafException(vmaf_hip_last_error());
+        if (vmaf_hip_extract_host_raw_async(e, ref[b], dis[b], src.bps, stride, plane, n, at > 0 ? 1 : 0, out[slot].data()))
             throw VmafException(vmaf_hip_last_error());
-        pend[fill] = { at, n };
+        pend[slot] = { at, n, b };
         ++inflight;
-        fill ^= 1;
+        slot ^= 1;
+        t_gpu += ms(t0, t1); t_read += ms(t1, t2); t_enq += ms(t2, now());
     }
-    trace("shard: all batches enqueued");
+    std::snprintf(msg, sizeof msg, "shard: all batches enqueued (this thread waited %.1f ms for the GPU, %.1f ms for the readers, enqueued for %.1f ms)",
+                  t_gpu, t_read, t_enq);
+    trace(msg);
     while (inflight) collect();
     trace("shard: done");
 }
 
 // Frame-range sharding of ONE video over the devices of VMAF_HIP_DEVICES: device g scores frames [g*F/G, (g+1)*F/G) on its
 // own host thread with its own engine and reads; no exchange between shards (the halo is re-read), motion2 and the fusion
-// run after all shards have delivered (vmaf.cpp:375-379 needs motion[i+1] across the shard edge).
+// run after all shards have delivered (vmaf.cpp:375-379 needs motion[i+1] across the shard edge).  A shard that fails
+// stops the others at their next frame; the failure with the lowest frame index is the one reported.
 void extract_atoms_sharded(const FrameSource &src, int w, int h, bool scalar_order, const MetricFlags &mf, std::vector<double> &atoms,
                            std::vector<double> &metrics)
 {
@@ -343,18 +460,18 @@ void extract_atoms_sharded(const FrameSource &src, int w, int h, bool scalar_ord
     const int G = (int)devices.size();
     atoms.assign((size_t)F * kAtoms, 0.0);
     if (mf.any()) metrics.assign((size_t)F * VMAF_HIP_METRICS, 0.0);
-    std::vector<std::string> errors(G);
-    std::vector<std::thread> th;
-    for (int g = 0; g < G; ++g) {
+    ShardAbort abort;
+    auto shard = [&](int g) {
         const long start = F * g / G, stop = F * (g + 1) / G;
-        th.emplace_back([&, g, start, stop] {
-            try { extract_shard(src, devices[g], w, h, scalar_order, mf, start, stop, fetch_threads(G), atoms.data(), mf.any() ? metrics.data() : nullptr); }
-            catch (const std::exception &ex) { errors[g] = ex.what(); if (errors[g].empty()) errors[g] = "unknown error"; }
-        });
-    }
+        try { extract_shard(src, devices[g], w, h, scalar_order, mf, start, stop, fetch_threads(G), atoms.data(), mf.any() ? metrics.data() : nullptr, abort); }
+        catch (const ShardFailure &f) { if (f.frame >= 0 || !abort.stop.load()) abort.fail(f.frame, f.msg); }
+        catch (const std::exception &ex) { abort.fail(-1, *ex.what() ? ex.what() : "unknown error"); }
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(shard, g);
+    shard(0);                                                      // the first shard on the calling thread: one thread start less
     for (auto &t : th) t.join();
-    for (int g = 0; g < G; ++g)
-        if (!errors[g].empty()) throw VmafException(errors[g]);
+    if (abort.stop.load()) throw VmafException(abort.msg.empty() ? std::string("unknown error") : abort.msg);
 }
 
 const char *kKnownFeatures[] = { "adm2", "adm_scale0", "adm_scale1", "adm_scale2", "adm_scale3", "motion", "vif_scale0",

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <vector>
 #include <cstdarg>
@@ -37,6 +38,15 @@ int fail(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return 1;
+}
+
+// VMAF_HIP_TRACE=1: wall-clock milestones on stderr (where the fixed cost of a short run goes; libvmaf.cpp has the same switch)
+void trace(const char *what)
+{
+    static const bool on = getenv("VMAF_HIP_TRACE") && atoi(getenv("VMAF_HIP_TRACE")) != 0;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[vmaf_hip engine %8.3f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -105,6 +115,7 @@ struct vmaf_hip_engine : Geometry, FeatureBuffers {
     hipEvent_t ev_copy[kDepth] = {};
     unsigned char *raw_ref[kDepth] = {}, *raw_dis[kDepth] = {};   // allocated on first use
     float *carry[2] = {};
+    unsigned char *arena = nullptr;                              // ONE device allocation: pyramid planes, LL bands, carry planes, reduced sums
     int carry_cur = 0;
     bool carry_valid = false;
     float *stage_ref[kDepth] = {}, *stage_dis[kDepth] = {};      // fp32 planes, allocated on first use: the fp32 host path, and raw input with metrics on
@@ -221,6 +232,14 @@ void geometry_init(Geometry *g, int width, int height, int max_batch)
 }
 
 int alloc_planes(float **p, size_t floats) { HIP_TRY(hipMalloc((void **)p, floats * sizeof(float))); return 0; }
+
+// carve n elements, 256-byte aligned, from a buffer; only sizes the layout when base is null
+template <typename T> T *carve(unsigned char *base, size_t *off, size_t n)
+{
+    const size_t at = (*off + 255) & ~(size_t)255;
+    *off = at + n * sizeof(T);
+    return base ? reinterpret_cast<T *>(base + at) : nullptr;
+}
 
 // Where a chain reads its current scale from: the caller's picture at scale 0 (fp32 planes, or raw 8/16-bit luma that the
 // kernels widen in their loads), the fp32 pyramid buffers afterwards.  Strides in samples.
@@ -466,14 +485,6 @@ int noalloc_scratch(int device, unsigned char **out)
     return 0;
 }
 
-// carve n bytes, 256-byte aligned, from the scratch area; only sizes the layout when base is null
-template <typename T> T *carve(unsigned char *base, size_t *off, size_t n)
-{
-    const size_t at = (*off + 255) & ~(size_t)255;
-    *off = at + n * sizeof(T);
-    return base ? reinterpret_cast<T *>(base + at) : nullptr;
-}
-
 struct NoallocLayout { FeatureBuffers b; float *carry = nullptr; size_t bytes = 0; };
 
 NoallocLayout noalloc_layout(const Geometry &g, int nframes, unsigned char *base)
@@ -515,9 +526,12 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     if (width > 16384 || height > 16384) return fail("frame %dx%d too large", width, height);
     if (max_batch < 1 || max_batch > 4096) return fail("max_batch %d outside 1..4096", max_batch);
     int ndev = 0;
+    trace("create: start");
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail("device %d outside 0..%d", device, ndev - 1);
+    trace("create: device count known (runtime initialised)");
     HIP_TRY(hipSetDevice(device));
+    trace("create: device set");
 
     vmaf_hip_engine *e = new (std::nothrow) vmaf_hip_engine();
     if (!e) return fail("out of host memory");
@@ -532,11 +546,13 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     const char *ser = getenv("VMAF_HIP_SERIAL");
     e->serial = ser && *ser && *ser != '0';
     if (hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
+    trace("create: first stream");
     if (e->serial) { e->s_adm = e->s_main; e->s_mot = e->s_main; e->s_copy = e->s_main; e->s_red = e->s_main; }
     else if (hipStreamCreateWithFlags(&e->s_red, hipStreamNonBlocking) != hipSuccess ||
              hipStreamCreateWithFlags(&e->s_adm, hipStreamNonBlocking) != hipSuccess ||
              hipStreamCreateWithFlags(&e->s_mot, hipStreamNonBlocking) != hipSuccess ||
              hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return cleanup(); }
+    trace("create: other streams");
     hipEvent_t *evs[] = { &e->ev_in, &e->ev_adm, &e->ev_mot, &e->ev_vif, &e->ev_copy[0], &e->ev_copy[1] };
     for (auto ev : evs)
         if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
@@ -546,24 +562,30 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
             if (hipEventCreate(ev) != hipSuccess) { fail("hipEventCreate failed"); return cleanup(); }
     }
 
-    for (int s = 1; s < 4 && !rc; ++s) {
-        rc |= alloc_planes(&e->vif_ref[s], B * e->vw[s] * e->vh[s]);
-        rc |= alloc_planes(&e->vif_dis[s], B * e->vw[s] * e->vh[s]);
-        rc |= alloc_planes(&e->adm_ref[s], B * e->aw[s] * e->ah[s]);
-        rc |= alloc_planes(&e->adm_dis[s], B * e->aw[s] * e->ah[s]);
+    trace("create: streams and events");
+    // one device allocation for everything whose size is fixed at creation (an allocation, and above all a free, costs a
+    // device synchronisation: 21 separate ones made create + destroy ~8 ms of a short run)
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        size_t off = 0;
+        for (int s = 1; s < 4; ++s) {
+            e->vif_ref[s] = carve<float>(e->arena, &off, B * e->vw[s] * e->vh[s]);
+            e->vif_dis[s] = carve<float>(e->arena, &off, B * e->vw[s] * e->vh[s]);
+            e->adm_ref[s] = carve<float>(e->arena, &off, B * e->aw[s] * e->ah[s]);
+            e->adm_dis[s] = carve<float>(e->arena, &off, B * e->aw[s] * e->ah[s]);
+        }
+        for (int i = 0; i < 2; ++i) e->carry[i] = carve<float>(e->arena, &off, (size_t)width * height);
+        for (int i = 0; i < kDepth; ++i) e->sums_set[i] = carve<double>(e->arena, &off, B * VK_NSUMS);
+        if (pass == 0 && hipMalloc((void **)&e->arena, off) != hipSuccess) rc = fail("hipMalloc(engine buffers, %zu bytes) failed", off);
     }
-    for (int i = 0; i < 2 && !rc; ++i) rc |= alloc_planes(&e->carry[i], (size_t)width * height);
-
+    e->sums_dev = e->sums_set[0];
     const size_t off = e->part_total;
     for (int i = 0; i < kDepth && !rc; ++i)
         if (hipMalloc((void **)&e->partials_set[i], off * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(partials) failed");
     e->partials = e->partials_set[0];
-    for (int i = 0; i < kDepth && !rc; ++i)
-        if (hipMalloc((void **)&e->sums_set[i], B * VK_NSUMS * sizeof(double)) != hipSuccess) rc = fail("hipMalloc(sums) failed");
-    e->sums_dev = e->sums_set[0];
-    for (int i = 0; i < kDepth && !rc; ++i)
-        if (hipHostMalloc((void **)&e->sums_host[i], B * VK_NSUMS * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail("hipHostMalloc failed");
+    if (!rc && hipHostMalloc((void **)&e->sums_host[0], kDepth * B * VK_NSUMS * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail("hipHostMalloc failed");
+    for (int i = 1; i < kDepth && !rc; ++i) e->sums_host[i] = e->sums_host[0] + (size_t)i * B * VK_NSUMS;
     if (rc) return cleanup();
+    trace("create: device and host buffers");
     *out = e;
     return 0;
 }
@@ -573,11 +595,7 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
-    for (int s = 0; s < 4; ++s) {
-        (void)hipFree(e->vif_ref[s]); (void)hipFree(e->vif_dis[s]);
-        (void)hipFree(e->adm_ref[s]); (void)hipFree(e->adm_dis[s]);
-    }
-    (void)hipFree(e->carry[0]); (void)hipFree(e->carry[1]);
+    (void)hipFree(e->arena);
     for (int i = 0; i < kDepth; ++i) {
         (void)hipFree(e->stage_ref[i]); (void)hipFree(e->stage_dis[i]);
         (void)hipFree(e->raw_ref[i]); (void)hipFree(e->raw_dis[i]);
@@ -587,11 +605,11 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
     for (int i = 1; i < 5; ++i) { (void)hipFree(e->ms_ref[i]); (void)hipFree(e->ms_dis[i]); }
     if (e->ev_iqa) (void)hipEventDestroy(e->ev_iqa);
     if (e->s_iqa && e->s_iqa != e->s_main) (void)hipStreamDestroy(e->s_iqa);
-    for (int i = 0; i < kDepth; ++i) { (void)hipFree(e->partials_set[i]); (void)hipFree(e->sums_set[i]); }
+    for (int i = 0; i < kDepth; ++i) (void)hipFree(e->partials_set[i]);
     hipEvent_t evs[] = { e->ev_in, e->ev_adm, e->ev_mot, e->ev_vif, e->ev_copy[0], e->ev_copy[1] };
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < kDepth; ++i) {
-        if (e->sums_host[i]) (void)hipHostFree(e->sums_host[i]);
+        if (i == 0 && e->sums_host[0]) (void)hipHostFree(e->sums_host[0]);
         hipEvent_t tevs[] = { e->ev_t0[i], e->ev_t1[i], e->ev_k0[i], e->ev_k1[i], e->ev_done[i] };
         for (auto ev : tevs) if (ev) (void)hipEventDestroy(ev);
     }
