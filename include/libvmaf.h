@@ -85,10 +85,16 @@ int vmaf_amd_model_feature_names(const char *model_path, int *n_features, char *
  * (features_out: [nframes][features_capacity], may be NULL; the first D columns of a row are written, D =
  * vmaf_amd_model_feature_names' n_features; features_capacity < D is an error, nothing is written).
  * The SVR runs on `device`.  Returns 0 on success.
+ * _v2 is the form with the capacity argument.  The symbol without the suffix keeps the prototype it was first shipped
+ * with (no capacity: features_out rows are exactly D wide, the caller sizes them from vmaf_amd_model_feature_names), so
+ * that a program built against that prototype still gets the arguments it passes; new code uses _v2.
  */
+int vmaf_amd_predict_from_atoms_v2(const char *model_path, const double *atoms, int nframes, int disable_clip,
+                                   int enable_transform, int device, double *vmaf_out, double *features_out,
+                                   int features_capacity, char *errbuf, int errbuf_len);
 int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip,
                                 int enable_transform, int device, double *vmaf_out, double *features_out,
-                                int features_capacity, char *errbuf, int errbuf_len);
+                                char *errbuf, int errbuf_len);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -23,11 +23,13 @@
  *     destroyed concurrently from different threads, on the same or on different devices
  *     (tests/test_gpu_parity.py::test_engines_on_concurrent_host_threads).  vmaf_hip_engine_destroy waits for the whole
  *     device to go idle, so it may stall (never corrupt) other engines' calls on that device.
- *   - vmaf_hip_last_error() is per calling thread.  vmaf_hip_svm_predict, vmaf_hip_host_alloc/free and
- *     vmaf_hip_device_count keep no state and may be called from any thread at any time.
+ *   - vmaf_hip_last_error() is per calling thread.  vmaf_hip_host_alloc/free and vmaf_hip_device_count keep no state;
+ *     vmaf_hip_svm_predict keeps the model and its work buffers on the GPU between calls behind one lock per GPU: all
+ *     three may be called from any thread at any time.
  *   - Every call makes the engine's device current on the calling thread (hipSetDevice) and leaves it so.
- *   - vmaf_hip_extract_device_noalloc uses one static scratch area per GPU: calls on the same GPU must not overlap
- *     (see its comment); it is independent of engines.
+ *   - vmaf_hip_extract_device_noalloc uses one static scratch area per GPU: calls on the same GPU must not overlap - a
+ *     call that arrives while another one is running on that GPU is refused with an error (see its comment); it is
+ *     independent of engines.
  * Debug / profiling hooks live in include/vmaf_hip_debug.h.
  */
 #ifndef VMAF_HIP_H_
@@ -188,7 +190,10 @@ int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes);
  * hipMalloc / hipFree / hipHostMalloc and creates no stream or event.  A request that does not fit is refused with a
  * message (vmaf_hip_noalloc_scratch_needed tells in advance; 0 = invalid arguments): 32 MiB hold e.g. two 1920x1080
  * frames, 6 of 1280x720 or 33 of 576x324 per call; one 3840x2160 frame (74 MB) does not fit.  All calls on one GPU share that GPU's array: calls that
- * overlap in time on the same GPU (other threads, other streams) race and must be serialised by the caller.
+ * overlap in time on the same GPU (other threads, other streams) would race, so a call that finds another one running on
+ * its GPU fails with a message instead (a per-GPU flag, held from the first launch to the final synchronisation); callers
+ * serialise.  The array costs its 32 MiB of device memory on every GPU the process touches, whether this entry point is
+ * ever called or not.
  */
 #define VMAF_HIP_NOALLOC_SCRATCH_BYTES (32u << 20)
 size_t vmaf_hip_noalloc_scratch_needed(int width, int height, int nframes);

@@ -193,6 +193,50 @@ def test_run_vmaf_in_batch_text_output(tmp_path):
 
 
 @pytest.mark.gpu
+def test_batch_of_720p_pairs_over_three_workers(tmp_path):
+    """BASELINE.json configs[3] in small: 18 pairs of 1280x720 (two lengths, 8 and 5 frames, so that the longest-first
+    assignment has something to balance) through run_vmaf_in_batch --parallelize with three worker processes on the one
+    GPU (VMAF_HIP_DEVICES=0,0,0).  Output in input order (asset_id = line index, run_vmaf_in_batch:87-96), every pair's
+    scores equal to the single-process run, and the workers' loads apart by at most one pair's cost."""
+    r, d = synth.make_clip(1280, 720, 8, seed=720)
+    lines, sizes = [], []
+    for i in range(18):
+        n = 8 if i % 3 != 1 else 5                                   # 12 long pairs, 6 short ones
+        sh = i % 4                                                   # four different distorted clips
+        rp, dp = str(tmp_path / f"r{i}.yuv"), str(tmp_path / f"d{i}.yuv")
+        synth.write_yuv(rp, r[:n], "yuv420p")
+        synth.write_yuv(dp, np.roll(d[:n], sh, axis=2), "yuv420p")
+        lines.append(f"yuv420p 1280 720 {rp} {dp}")
+        sizes.append(n)
+    f = tmp_path / "batch.txt"
+    f.write_text("# eighteen pairs\n" + "\n".join(lines) + "\n")
+    one = subprocess.run(BATCH + [str(f), "--out-fmt", "json"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr
+    par = subprocess.run(BATCH + [str(f), "--out-fmt", "json", "--parallelize"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, VMAF_HIP_DEVICES="0,0,0", VMAF_HIP_TRACE="1"))
+    assert par.returncode == 0, par.stderr
+    assert par.stdout == one.stdout                                  # same bytes: order, frame counts, every score
+    docs, dec, text = [], json.JSONDecoder(), one.stdout[one.stdout.index("{"):].strip()  # after "Skip commented line: ..."
+    while text:                                                      # one indented JSON document per asset, back to back
+        doc, end = dec.raw_decode(text)
+        docs.append(doc)
+        text = text[end:].lstrip()
+    assert len(docs) == 18
+    for i, (doc, n) in enumerate(zip(docs, sizes)):
+        assert len(doc["frames"]) == n
+    # pairs with the same distortion and length score the same, different shifts differ
+    assert docs[0]["aggregate"]["VMAF_score"] == docs[12]["aggregate"]["VMAF_score"]        # i = 0 and 12: same shift, same length
+    assert docs[0]["aggregate"]["VMAF_score"] != docs[2]["aggregate"]["VMAF_score"]
+    workers = re.findall(r"worker (\d+) \(device 0\): assets \[([0-9, ]*)\], cost (\d+)", par.stderr)
+    assert len(workers) == 3
+    seen = sorted(int(x) for _, a, _ in workers for x in a.split(",") if x.strip())
+    assert seen == list(range(18))
+    loads = [int(c) for _, _, c in workers]
+    one_pair = 1280 * 720 * os.path.getsize(str(tmp_path / "r0.yuv"))
+    assert max(loads) - min(loads) <= one_pair, loads
+
+
+@pytest.mark.gpu
 def test_run_vmaf_xml_is_what_python2_printed(tmp_path):
     """run_vmaf --out-fmt xml (result.py:178-224 under Python 2, pinned by python/test/result_test.py:148-160):
     attributes in plain string order - the VMAF_* scores, then frameNum / method - and values through str(float)."""

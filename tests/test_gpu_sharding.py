@@ -59,6 +59,25 @@ def test_vmafossexec_shards_give_byte_identical_logs(clip_1080p, tmp_path):
     assert len(frames) == 12 and all(abs(float(v) - x) < 5e-4 * max(1.0, x) for v, x in zip(frames, vm))
 
 
+def test_four_shards_keep_their_reader_threads(clip_1080p, tmp_path):
+    """The reader threads are a per-shard resource: four shards of one video (here on the one GPU) each get at least four
+    (round 2 divided a process-wide default of 8 over the shards: 8 GPUs -> one copying thread per shard, i.e. the whole
+    node at about the rate of one well-fed GPU).  The shard lines of VMAF_HIP_TRACE name range and readers; the log of the
+    sharded run is the unsharded one's byte for byte."""
+    rp, dp, _, _ = clip_1080p
+    env = {k: v for k, v in os.environ.items() if k != "VMAF_HIP_READ_THREADS"}
+    base = _exec(rp, dp, 1920, 1080, "yuv420p", str(tmp_path / "a.xml"), {})
+    log = str(tmp_path / "b.xml")
+    p = subprocess.run([EXE, "yuv420p", "1920", "1080", rp, dp, MODEL, "--log", log], capture_output=True, text=True, timeout=300,
+                       env=dict(env, VMAF_HIP_DEVICES="0,0,0,0", VMAF_HIP_TRACE="1"))
+    assert p.returncode == 0, p.stderr
+    assert (re.sub(r"Exec FPS: [0-9.]+", "", p.stdout), re.sub(r'execFps="[^"]*"', "", open(log).read())) == base
+    shards = sorted((int(a), int(b), int(n)) for a, b, n in re.findall(r"shard: frames \[(\d+), (\d+)\), (\d+) reader threads", p.stderr))
+    assert [(a, b) for a, b, _ in shards] == [(0, 3), (3, 6), (6, 9), (9, 12)]
+    assert all(n >= 4 for _, _, n in shards), shards
+    assert cli._read_threads(8) >= 4 and cli._read_threads(1) >= 4
+
+
 def test_sharded_metrics_and_more_shards_than_frames(tmp_path):
     r, d = synth.make_clip(576, 324, 5, seed=5, cuts=(2,))
     rp, dp = str(tmp_path / "r.yuv"), str(tmp_path / "d.yuv")

@@ -70,3 +70,33 @@ def test_noalloc_entry_refuses_what_does_not_fit():
         binding.extract_device_noalloc(t, t, 64, 48, 1, row_stride_bytes=128)
     with pytest.raises(vmaf_amd.VmafHipError, match="null pointer"):
         binding.extract_device_noalloc(0, t, 64, 48, 1)
+
+
+def test_overlapping_noalloc_calls_are_refused_not_raced():
+    """The calls of one GPU share its static scratch area.  Four host threads call at once (ctypes releases the GIL): every
+    call either returns the right atoms or is refused with the 'another call' message - never a silently mixed result -
+    and at least one goes through."""
+    torch = pytest.importorskip("torch")
+    import threading
+    w, h, n = 640, 360, 4
+    tr, td = _device_clip(torch, w, h, n, 33)
+    torch.cuda.synchronize()
+    want = _engine_atoms(tr, td, w, h, n)
+    ok, refused, wrong = [], [], []
+
+    def worker():
+        for _ in range(6):
+            try:
+                got = binding.extract_device_noalloc(tr, td, w, h, n)
+                (ok if np.array_equal(got, want) else wrong).append(1)
+            except vmaf_amd.VmafHipError as exc:
+                (refused if "another call" in str(exc) else wrong).append(str(exc))
+
+    th = [threading.Thread(target=worker) for _ in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not wrong, wrong[:3]
+    assert ok and len(ok) + len(refused) == 24
+    assert np.array_equal(binding.extract_device_noalloc(tr, td, w, h, n), want)      # the flag is released again

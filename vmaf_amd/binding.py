@@ -83,7 +83,8 @@ def load_library():
                                         i, i, i, i, i, i, i, C.c_char_p, C.c_char_p, i]
     L.compute_vmaf_raw_seekable_noexcept.argtypes = [_dp, C.c_char_p, i, i, C.c_long, READ_FRAME_RAW_AT, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                                      i, i, i, i, i, i, i, C.c_char_p, C.c_char_p, i]
-    L.vmaf_amd_predict_from_atoms.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, i, C.c_char_p, i]
+    L.vmaf_amd_predict_from_atoms_v2.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, i, C.c_char_p, i]
+    L.vmaf_amd_predict_from_atoms.argtypes = [C.c_char_p, _dp, i, i, i, i, _dp, _dp, C.c_char_p, i]
     L.vmaf_amd_model_feature_names.argtypes = [C.c_char_p, C.POINTER(i), C.c_char_p, i, C.c_char_p, i]
     _lib = L
     return L
@@ -370,7 +371,7 @@ def predict_from_atoms(atoms, model_path=DEFAULT_MODEL, disable_clip=False, enab
     vm = np.zeros(F)
     feats = np.zeros((F, D))
     err = C.create_string_buffer(1024)
-    if L.vmaf_amd_predict_from_atoms(model_path.encode(), atoms.ctypes.data_as(_dp), F, int(disable_clip),
+    if L.vmaf_amd_predict_from_atoms_v2(model_path.encode(), atoms.ctypes.data_as(_dp), F, int(disable_clip),
                                      int(enable_transform), device, vm.ctypes.data_as(_dp), feats.ctypes.data_as(_dp), D,
                                      err, 1024):
         raise VmafHipError(err.value.decode(errors="replace"))

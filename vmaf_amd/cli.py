@@ -182,9 +182,6 @@ class Result:
 
 
 # ---------------------------------------------------------------------------------- scoring
-PREAD_PLANES = os.environ.get('VMAF_HIP_PY_PREAD', '1') not in ('', '0')     # 0: copy out of the memory map instead
-
-
 class LumaFile:
     """A raw YUV file seen as its luma planes, without reading it: a memory map plus the frame geometry.  The reference
     reads one frame at a time (feature/src/common/frame.c:26-129: Y plane, then fread-skips the chroma); here a batch of
@@ -202,7 +199,7 @@ class LumaFile:
         if total - self.frames * self.frame_samples >= n:
             self.frames += 1                               # a last frame with short chroma is still scored (frame.c:83-87)
         self.mm = np.memmap(path, dtype=self.dtype, mode='r') if total else np.zeros(0, self.dtype)
-        self.fd = os.open(path, os.O_RDONLY) if total and PREAD_PLANES else -1
+        self.fd = os.open(path, os.O_RDONLY) if total else -1
 
     def __del__(self):
         if getattr(self, 'fd', -1) >= 0:
@@ -298,12 +295,20 @@ def _batch_size(w, h):
 
 
 def _read_threads(shards=1):
-    """Reader threads per shard: VMAF_HIP_READ_THREADS (default 8, the knob vmafossexec has too) split over the shards."""
+    """Reader threads PER SHARD, the rule of vmafossexec (libvmaf.cpp fetch_threads): VMAF_HIP_READ_THREADS if set, else
+    min(8, CPUs of this process / shards) but never fewer than 4 - one copying thread moves ~8 GB/s out of the page cache,
+    a shard's PCIe link ~51 GB/s, so eight shards with one reader each would together run at the rate of ONE well-fed GPU."""
     try:
-        n = int(os.environ.get("VMAF_HIP_READ_THREADS", "8"))
+        n = int(os.environ.get("VMAF_HIP_READ_THREADS", "0"))
     except ValueError:
-        n = 8
-    return max(1, min(n, os.cpu_count() or 1) // max(1, shards))
+        n = 0
+    if n > 0:
+        return min(n, 64)
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 8
+    return max(4, min(8, cpus // max(1, shards)))
 
 
 def _stream_range(eng, ref, dis, start, stop, atoms, readers=1):
@@ -604,6 +609,10 @@ def run_vmaf_in_batch_main(argv):
         import multiprocessing as mp
         costs = [a.asset_dict['width'] * a.asset_dict['height'] * max(1, os.path.getsize(a.ref_path)) for a in assets]
         parts = sharding.assign_pairs(costs, ndev)
+        if os.environ.get("VMAF_HIP_TRACE", "0") not in ("", "0"):
+            for d in range(ndev):                              # who scores what (tests check the balance through this)
+                print("run_vmaf_in_batch: worker %d (device %d): assets %s, cost %d" % (d, devices[d], parts[d], sum(costs[i] for i in parts[d])),
+                      file=sys.stderr)
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         procs = [ctx.Process(target=_batch_worker, args=(devices[d], [(i, assets[i]) for i in parts[d]], model_path, phone_model, q))

@@ -809,8 +809,8 @@ int vmaf_amd_model_feature_names(const char *model_path, int *n_features, char *
     }
 }
 
-int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip, int enable_transform,
-                                int device, double *vmaf_out, double *features_out, int features_capacity, char *errbuf, int errbuf_len)
+int vmaf_amd_predict_from_atoms_v2(const char *model_path, const double *atoms, int nframes, int disable_clip, int enable_transform,
+                                   int device, double *vmaf_out, double *features_out, int features_capacity, char *errbuf, int errbuf_len)
 {
     try {
         if (!model_path || !atoms || !vmaf_out || nframes <= 0) throw VmafException("bad argument");
@@ -833,6 +833,16 @@ int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int
         copy_err(errbuf, errbuf_len, e.what());
         return 1;
     }
+}
+
+// the prototype this symbol was first shipped with: features_out rows are exactly as wide as the model has features
+int vmaf_amd_predict_from_atoms(const char *model_path, const double *atoms, int nframes, int disable_clip, int enable_transform,
+                                int device, double *vmaf_out, double *features_out, char *errbuf, int errbuf_len)
+{
+    int D = 0;
+    if (features_out && vmaf_amd_model_feature_names(model_path, &D, nullptr, 0, errbuf, errbuf_len)) return 1;
+    return vmaf_amd_predict_from_atoms_v2(model_path, atoms, nframes, disable_clip, enable_transform, device, vmaf_out, features_out, D,
+                                          errbuf, errbuf_len);
 }
 
 }  // extern "C"

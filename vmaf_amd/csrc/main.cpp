@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,6 +21,53 @@
 
 namespace {
 
+// One helper thread for the whole run of the sequential (FIFO) path: it reads the dis plane of every frame while the calling
+// thread reads the ref plane (a thread started per frame costs more than it saves on small frames).
+class SideReader {
+public:
+    ~SideReader()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        if (t_.joinable()) t_.join();
+    }
+    void start(std::function<int()> job)
+    {
+        if (!t_.joinable()) t_ = std::thread([this] { loop(); });
+        { std::lock_guard<std::mutex> l(m_); job_ = std::move(job); busy_ = true; }
+        cv_.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return !busy_; });
+        return rc_;
+    }
+
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            cv_.wait(l, [this] { return stop_ || (busy_ && job_); });
+            if (stop_) return;
+            std::function<int()> job = std::move(job_);
+            job_ = nullptr;
+            l.unlock();
+            const int rc = job();
+            l.lock();
+            rc_ = rc; busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::thread t_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    bool busy_ = false, stop_ = false;
+    int rc_ = 0;
+};
+
 struct YuvPair {
     FILE *ref = nullptr, *dis = nullptr;
     int width = 0, height = 0;
@@ -26,6 +76,8 @@ struct YuvPair {
     std::vector<unsigned char> row;
     // regular files (compute_vmaf_raw_seekable): frames are read by position, from several shard threads at once
     size_t luma_bytes = 0, frame_bytes = 0;
+    SideReader side;                    // sequential raw path only
+    std::vector<unsigned char> dis_scratch;
 };
 
 // One luma plane -> fp32 in 8-bit units (10-bit: value / 4.0, file_io.c:159-163). 0 ok, 1 short read.
@@ -80,12 +132,11 @@ int read_frame_raw_cb(void *ref_luma, void *dis_luma, int stride_byte, void *use
     const size_t bytes = (size_t)stride_byte * s.height;
     // the two files are read side by side: one copy from the page cache into page-locked memory per thread is what
     // bounds the file-to-score rate of this CLI
-    int dis_rc = 0;
-    std::vector<unsigned char> dis_scratch;
-    std::thread t([&] {
-        if (std::fread(dis_luma, 1, bytes, s.dis) != bytes) { dis_rc = std::feof(s.dis) ? 2 : 1; return; }
-        dis_scratch.resize(1 << 20);
-        skip_chroma(s.dis, s, (float *)dis_scratch.data(), dis_scratch.size());
+    s.side.start([&s, dis_luma, bytes]() -> int {
+        if (std::fread(dis_luma, 1, bytes, s.dis) != bytes) return std::feof(s.dis) ? 2 : 1;
+        s.dis_scratch.resize(1 << 20);
+        skip_chroma(s.dis, s, (float *)s.dis_scratch.data(), s.dis_scratch.size());
+        return 0;
     });
     int ref_rc = 0;
     if (std::fread(ref_luma, 1, bytes, s.ref) != bytes) ref_rc = std::feof(s.ref) ? 2 : 1;
@@ -93,7 +144,7 @@ int read_frame_raw_cb(void *ref_luma, void *dis_luma, int stride_byte, void *use
         s.row.resize(1 << 20);
         skip_chroma(s.ref, s, (float *)s.row.data(), s.row.size());
     }
-    t.join();
+    const int dis_rc = s.side.wait();
     return ref_rc ? ref_rc : dis_rc;                             // frame.c:48-78: the ref read is checked first
 }
 

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 
@@ -321,16 +322,14 @@ int enqueue_batch(vmaf_hip_engine *e, const void *in_ref, const void *in_dis, in
     // VALUs on its own, so they start after it and share the GPU with VIF scales 1-3, which are too small to fill it
     // (+1.4 % throughput, and the dominant kernel runs undisturbed).  In the fused order that launch is 35 % shorter and
     // leaves issue slots: there they start at once (+2 %).  Measured with bench.py, both ways, both orders.
-    static const int sched_env = getenv("VMAF_HIP_ADM_START") ? atoi(getenv("VMAF_HIP_ADM_START")) : -1;   // 0 late, 1 at once
-    const bool adm_early = sched_env >= 0 ? sched_env != 0 : e->order == 2;
+    const bool adm_early = e->order == 2;
     if (adm_early) {
         HIP_TRY(hipStreamWaitEvent(e->s_adm, e->ev_in, 0));
         HIP_TRY(hipStreamWaitEvent(e->s_mot, e->ev_in, 0));
     }
 
     // ---- optional metrics on their own stream (combo.c:168-230: before the -128 offset, i.e. on the planes as given)
-    static const bool psnr_fuse_env = !getenv("VMAF_HIP_PSNR_FUSED") || atoi(getenv("VMAF_HIP_PSNR_FUSED")) != 0;   // 0: A/B measurements
-    const bool psnr_fused = psnr_fuse_env && e->m_psnr && e->m_ms;
+    const bool psnr_fused = e->m_psnr && e->m_ms;
     if (any_metric) {
         hipStream_t q = e->s_iqa;
         HIP_TRY(hipStreamWaitEvent(q, e->ev_in, 0));
@@ -393,9 +392,8 @@ int enqueue_batch(vmaf_hip_engine *e, const void *in_ref, const void *in_dis, in
     // launch while the short ADM tail of this batch (three launches that cannot fill the GPU) is still running: at 30 frames
     // of 1080p per batch 29.8k -> 31.2k frames/s, within 3 % of the rate of large batches.  Large batches amortise that tail
     // anyway (+1 % at 120 frames) and keep the join on s_main, where the dominant kernel runs undisturbed by the
-    // previous batch (its launch stretches from 2.2 to 2.7 ms otherwise).  VMAF_HIP_TAIL_OVERLAP=0|1 overrides.
-    static const int tail_env = getenv("VMAF_HIP_TAIL_OVERLAP") ? atoi(getenv("VMAF_HIP_TAIL_OVERLAP")) : -1;
-    const bool tail_overlap = tail_env >= 0 ? tail_env != 0 : (size_t)nframes * e->w * e->h < (size_t)64 * 1920 * 1080;
+    // previous batch (its launch stretches from 2.2 to 2.7 ms otherwise).
+    const bool tail_overlap = (size_t)nframes * e->w * e->h < (size_t)64 * 1920 * 1080;
     hipStream_t s_join = tail_overlap ? e->s_red : e->s_main;
     if (s_join != e->s_main) {
         HIP_TRY(hipEventRecord(e->ev_vif, e->s_main));
@@ -470,6 +468,14 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_noalloc_mu;
 unsigned char *g_noalloc_ptr[kMaxDevices] = {};
+// one call at a time per GPU: the calls of a GPU share its scratch array, and two that overlapped would silently mix their
+// pyramids and partial sums.  A second call while one is running is refused with a message (no allocation, no waiting)
+std::atomic_flag g_noalloc_busy[kMaxDevices];
+struct NoallocBusy {
+    std::atomic_flag *f = nullptr;
+    bool take(int device) { if (g_noalloc_busy[device].test_and_set(std::memory_order_acquire)) return false; f = &g_noalloc_busy[device]; return true; }
+    ~NoallocBusy() { if (f) f->clear(std::memory_order_release); }
+};
 
 // device address of this GPU's copy of `scratch` (device must be current)
 int noalloc_scratch(int device, unsigned char **out)
@@ -971,6 +977,20 @@ int vmaf_hip_motion_seed_host(vmaf_hip_engine *e, const float *h_ref, size_t row
     return motion_seed_from_host(e, h_ref, 4, row_stride_bytes);
 }
 
+// Device side of the SVR, kept per GPU between calls: the model (support vectors and coefficients, ~12 KB for vmaf_v0.6.1)
+// is uploaded when it differs from the one already there, the feature / score buffers only grow.  A caller that fuses
+// batch after batch (bench.py, a serving loop) pays two small copies and one launch per call instead of four hipMalloc /
+// hipFree pairs.  One mutex per GPU: calls on one GPU are serialised, calls on different GPUs are independent.
+namespace {
+struct SvmDevice {
+    std::mutex mu;
+    std::vector<double> sv, coef;                                  // host copy of what d_sv / d_coef hold
+    double *d_sv = nullptr, *d_coef = nullptr, *d_x = nullptr, *d_out = nullptr;
+    size_t cap_n = 0, cap_dim = 0;                                 // d_x holds cap_n * cap_dim doubles, d_out cap_n
+};
+SvmDevice g_svm[kMaxDevices];
+}  // namespace
+
 int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho,
                          const double *x, int n, double *out)
 {
@@ -979,24 +999,35 @@ int vmaf_hip_svm_predict(int device, const double *sv, const double *coef, int n
     if (n == 0) return 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU path)");
-    if (device < 0 || device >= ndev) return fail("device %d outside 0..%d", device, ndev - 1);
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail("device %d outside 0..%d", device, std::min(ndev, kMaxDevices) - 1);
     HIP_TRY(hipSetDevice(device));
-    double *d_sv = nullptr, *d_coef = nullptr, *d_x = nullptr, *d_out = nullptr;
-    int rc = 0;
-    hipError_t err;
-#define SVM_TRY(expr) do { if (!rc && (err = (expr)) != hipSuccess) rc = fail("%s failed: %s", #expr, hipGetErrorString(err)); } while (0)
-    SVM_TRY(hipMalloc((void **)&d_sv, sizeof(double) * n_sv * dim));
-    SVM_TRY(hipMalloc((void **)&d_coef, sizeof(double) * n_sv));
-    SVM_TRY(hipMalloc((void **)&d_x, sizeof(double) * (size_t)n * dim));
-    SVM_TRY(hipMalloc((void **)&d_out, sizeof(double) * n));
-    SVM_TRY(hipMemcpy(d_sv, sv, sizeof(double) * n_sv * dim, hipMemcpyHostToDevice));
-    SVM_TRY(hipMemcpy(d_coef, coef, sizeof(double) * n_sv, hipMemcpyHostToDevice));
-    SVM_TRY(hipMemcpy(d_x, x, sizeof(double) * (size_t)n * dim, hipMemcpyHostToDevice));
-    SVM_TRY(vk_launch_svm(d_sv, d_coef, n_sv, dim, gamma, rho, d_x, n, d_out, nullptr));
-    SVM_TRY(hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
-#undef SVM_TRY
-    (void)hipFree(d_sv); (void)hipFree(d_coef); (void)hipFree(d_x); (void)hipFree(d_out);
-    return rc;
+    SvmDevice &c = g_svm[device];
+    std::lock_guard<std::mutex> lock(c.mu);
+    const size_t nsv = (size_t)n_sv * dim;
+    if (c.sv.size() != nsv || c.coef.size() != (size_t)n_sv || !std::equal(sv, sv + nsv, c.sv.begin()) || !std::equal(coef, coef + n_sv, c.coef.begin())) {
+        (void)hipFree(c.d_sv); (void)hipFree(c.d_coef);
+        c.d_sv = c.d_coef = nullptr;
+        c.sv.clear(); c.coef.clear();
+        HIP_TRY(hipMalloc((void **)&c.d_sv, sizeof(double) * nsv));
+        HIP_TRY(hipMalloc((void **)&c.d_coef, sizeof(double) * n_sv));
+        HIP_TRY(hipMemcpy(c.d_sv, sv, sizeof(double) * nsv, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.d_coef, coef, sizeof(double) * n_sv, hipMemcpyHostToDevice));
+        c.sv.assign(sv, sv + nsv);
+        c.coef.assign(coef, coef + n_sv);
+    }
+    if ((size_t)n * dim > c.cap_n * c.cap_dim || (size_t)n > c.cap_n) {
+        (void)hipFree(c.d_x); (void)hipFree(c.d_out);
+        c.d_x = c.d_out = nullptr;
+        c.cap_n = c.cap_dim = 0;
+        const size_t cap = std::max<size_t>((size_t)n, 1024);
+        HIP_TRY(hipMalloc((void **)&c.d_x, sizeof(double) * cap * dim));
+        HIP_TRY(hipMalloc((void **)&c.d_out, sizeof(double) * cap));
+        c.cap_n = cap; c.cap_dim = (size_t)dim;
+    }
+    HIP_TRY(hipMemcpy(c.d_x, x, sizeof(double) * (size_t)n * dim, hipMemcpyHostToDevice));
+    HIP_TRY(vk_launch_svm(c.d_sv, c.d_coef, n_sv, dim, gamma, rho, c.d_x, n, c.d_out, nullptr));
+    HIP_TRY(hipMemcpy(out, c.d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // ---- the entry point that allocates nothing (scratch area and layout: above, before the extern "C" block) ----
@@ -1026,6 +1057,9 @@ int vmaf_hip_extract_device_noalloc(int device, void *stream, const float *d_ref
     if (need > (size_t)VMAF_HIP_NOALLOC_SCRATCH_BYTES)
         return fail("%d frames of %dx%d need %zu bytes of scratch, the static area holds %zu: pass fewer frames per call or use an engine",
                     nframes, width, height, need, (size_t)VMAF_HIP_NOALLOC_SCRATCH_BYTES);
+    NoallocBusy busy;
+    if (!busy.take(device))
+        return fail("vmaf_hip_extract_device_noalloc: another call is using GPU %d's static scratch area (calls on one GPU must not overlap)", device);
     HIP_TRY(hipSetDevice(device));
     unsigned char *base = nullptr;
     if (noalloc_scratch(device, &base)) return 1;

@@ -833,24 +833,9 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
     // XCD-aware order: the workgroups one XCD receives (round-robin dispatch: blocks b, b+8, ..) cover a contiguous run of
     // tiles = a band of tile rows, so that the halo rows of vertically neighbouring tiles meet in that XCD's L2.  The rows
     // above and below the centre window are cheap (see in_window below), which would leave the XCDs with the outer bands
-    // idle at the end of the launch - so the band an XCD takes rotates from frame to frame (VMAF_ADM_ROWS_RR: the older
-    // scheme, tile rows dealt round-robin over the XCDs inside every frame: balanced too, but vertical neighbours never
-    // share an L2 and the input is read 1.21x)
+    // idle at the end of the launch - so the band an XCD takes rotates from frame to frame (dealing the tile rows round-robin
+    // over the XCDs inside every frame balances too, but vertical neighbours then never share an L2: input read 1.21x)
     int tile_id;
-#ifdef VMAF_ADM_ROWS_RR
-    {
-        const int nty = (bh + ADM_TH - 1) / ADM_TH;
-        const int i = xcd_tile_index(), p = i / ntx;           // p-th row of the permuted order
-        int row = 0, cum = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int nk = (nty - k + 7) / 8;                  // rows in run k
-            if (p >= cum && p < cum + nk) row = k + 8 * (p - cum);
-            cum += nk;
-        }
-        tile_id = row * ntx + (i - p * ntx);
-    }
-#else
     {
         const int b = blockIdx.x, nt = gridDim.x;
         const int xcd = (b + blockIdx.z) & 7;                  // the run this workgroup's XCD takes in this frame
@@ -875,7 +860,6 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
             }
         }
     }
-#endif
     const int cx0 = (tile_id % ntx) * ADM_TW, cy0 = (tile_id / ntx) * ADM_TH;   // first interior coefficient
     const T *fr = ref + (size_t)blockIdx.z * in_frame_stride;
     const T *fd = dis + (size_t)blockIdx.z * in_frame_stride;
@@ -1825,12 +1809,8 @@ extern "C" {
 
 // Planes at least 240 wide whose width is a multiple of 8 (no scalar-order columns but the two edge strips; the last tile
 // of a row may be narrower) take the workgroup-wide tiles of vif_stat_wg_kernel; every other size the wave-private 48x32
-// tiles.  VMAF_HIP_VIF_WG=0 turns the wide tiles off (A/B measurements).
-static bool vif_use_wg(int w, int h)
-{
-    static const int env = getenv("VMAF_HIP_VIF_WG") ? atoi(getenv("VMAF_HIP_VIF_WG")) : 1;
-    return env != 0 && w >= VWG_TW && w % 8 == 0 && h >= 17;
-}
+// tiles.
+static bool vif_use_wg(int w, int h) { return w >= VWG_TW && w % 8 == 0 && h >= 17; }
 int vk_vif_tiles(int w, int h)
 {
     if (vif_use_wg(w, h)) return ((w + VWG_TW - 1) / VWG_TW) * ((h + VWG_TH - 1) / VWG_TH);
@@ -1979,8 +1959,7 @@ hipError_t vk_launch_box_decimate(const float *src, size_t src_frame_stride, int
 hipError_t vk_launch_box_decimate_pair(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h, int f,
                                        float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s)
 {
-    static const int rows_env = getenv("VMAF_HIP_BOX_ROWS") ? atoi(getenv("VMAF_HIP_BOX_ROWS")) : 1;    // 0: A/B measurements
-    if (f > BOXR_FMAX || !rows_env) {
+    if (f > BOXR_FMAX) {
         hipError_t err = vk_launch_box_decimate(ref, src_frame_stride, src_row_stride, w, h, f, oref, sw, sh, nframes, s);
         return err != hipSuccess ? err : vk_launch_box_decimate(dis, src_frame_stride, src_row_stride, w, h, f, odis, sw, sh, nframes, s);
     }
