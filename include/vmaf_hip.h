@@ -171,9 +171,19 @@ int vmaf_hip_motion_seed_device_raw(vmaf_hip_engine *e, const void *d_ref, int b
  * out[nframes][VMAF_HIP_METRICS] = psnr, ssim, ms_ssim, ansnr, anpsnr (0 where not enabled).
  * vmaf_hip_engine_enable_ansnr adds ANSNR / ANPSNR (feature/src/ansnr.c:44-104, the atoms `ansnr` and `anpsnr` of
  * feature/src/all.c:148-176), computed like every caller of compute_ansnr does on the planes after the -128 offset.
+ *
+ * Arithmetic of SSIM / MS-SSIM: by default every window sum takes its products through v_fma_f64 (the product of two
+ * floats is exact in double, so a term enters the double running sum without the reference's intermediate rounding of
+ * img * k to float, iqa/convolve.c:129,144,262) and the per-pixel sqrt and divisions are hardware estimates + Newton steps:
+ * same tap order, same accumulator and result types, but not the reference's expression - scores within 1.3e-7 of it.
+ * vmaf_hip_engine_set_metrics_exact(e, 1) selects the reference's own expressions instead (float product, widened, added;
+ * IEEE double sqrt and division): per-pixel l, c, s bit-identical to iqa/ssim_tools.c:193-201, the scores equal to the
+ * reference's up to the order of the final double sum (~1e-15), for about half the metric throughput.  compute_vmaf sets
+ * it together with the scalar convolution order when disable_avx is given: that flag is the "most literal" mode.
  */
 #define VMAF_HIP_METRICS 5
 int vmaf_hip_engine_enable_metrics(vmaf_hip_engine *e, int do_psnr, int do_ssim, int do_ms_ssim, int ten_bit);
+int vmaf_hip_engine_set_metrics_exact(vmaf_hip_engine *e, int exact);
 int vmaf_hip_engine_enable_ansnr(vmaf_hip_engine *e, int ten_bit);
 int vmaf_hip_engine_get_metrics(vmaf_hip_engine *e, double *out, int nframes);
 

@@ -370,6 +370,30 @@ def test_psnr_ssim_ms_ssim_match_oracle(bits, w, h):
         assert abs(got[f, 2] - want[2]) < 1e-6, (f, got[f], want)
 
 
+@pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (10, 577, 325), (8, 200, 180), (8, 1280, 720), (8, 1030, 520)])
+def test_exact_metric_arithmetic_is_the_references(bits, w, h):
+    """vmaf_hip_engine_set_metrics_exact (what disable_avx selects in compute_vmaf): SSIM / MS-SSIM window sums as
+    iqa/convolve.c writes them (float product, widened, added) and IEEE sqrt / division per pixel, so every per-pixel
+    l, c, s is the reference's bit for bit; what remains is the order of the final double sums over the picture
+    (a tree here, a scan there: ~1e-16 relative per sum, and the scores pass through a float).  Held to 1e-9 against the
+    oracle - a thousand times closer than the default path's bound, which must differ from it somewhere to make the
+    test mean something."""
+    r, d = synth.make_clip(w, h, 2, bits=bits, seed=90 + w, dis_noise=9)
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    with vmaf_amd.Engine(w, h, max_batch=2) as e:
+        e.enable_metrics(ten_bit=bits == 10, exact=True)
+        e.extract(ref, dis)
+        exact = e.metrics.copy()
+        e.enable_metrics(ten_bit=bits == 10, exact=False)
+        e.extract(ref, dis)
+        fast = e.metrics.copy()
+    for f in range(2):
+        want = (oracle.ssim(ref[f], dis[f])[0], oracle.ms_ssim(ref[f], dis[f])[0])
+        assert abs(exact[f, 1] - want[0]) < 1e-9 and abs(exact[f, 2] - want[1]) < 1e-9, (f, exact[f], want)
+        assert abs(fast[f, 1] - want[0]) < 1e-6 and abs(fast[f, 2] - want[1]) < 1e-6
+    assert np.array_equal(exact[:, 0], fast[:, 0])                 # PSNR has one arithmetic
+
+
 def test_metrics_identical_frames_and_too_small_frames():
     ref, _ = _clip(192, 180, 2, seed=8)
     with vmaf_amd.Engine(192, 180) as e:

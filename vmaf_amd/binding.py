@@ -62,6 +62,7 @@ def load_library():
     L.vmaf_hip_motion_seed_device_raw.argtypes = [vp, vp, i, sz]
     L.vmaf_hip_engine_enable_metrics.argtypes = [vp, i, i, i, i]
     L.vmaf_hip_engine_enable_ansnr.argtypes = [vp, i]
+    L.vmaf_hip_engine_set_metrics_exact.argtypes = [vp, i]
     L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_engine_sync_oldest.argtypes = [vp]
@@ -127,10 +128,12 @@ class Engine:
     def __exit__(self, *a):
         self.close()
 
-    def enable_metrics(self, psnr=True, ssim=True, ms_ssim=True, ten_bit=False):
+    def enable_metrics(self, psnr=True, ssim=True, ms_ssim=True, ten_bit=False, exact=False):
         """Optional per-frame PSNR / SSIM / MS-SSIM (combo.c:168-230) next to the VMAF atoms; read them from
-        self.metrics [F,3] after extract() / extract_raw()."""
-        if self.L.vmaf_hip_engine_enable_metrics(self._h, int(psnr), int(ssim), int(ms_ssim), int(ten_bit)):
+        self.metrics [F,3] after extract() / extract_raw().  exact: SSIM / MS-SSIM in the reference's own expressions
+        (vmaf_hip_engine_set_metrics_exact) instead of exact-product fused sums."""
+        if self.L.vmaf_hip_engine_enable_metrics(self._h, int(psnr), int(ssim), int(ms_ssim), int(ten_bit)) or \
+                self.L.vmaf_hip_engine_set_metrics_exact(self._h, int(exact)):
             raise VmafHipError(_err(self.L))
         self._metrics_on = bool(psnr or ssim or ms_ssim)
 

@@ -125,6 +125,7 @@ struct vmaf_hip_engine : Geometry, FeatureBuffers {
 
     // optional metrics (combo.c:168-230): PSNR, SSIM, MS-SSIM on the un-offset planes
     bool m_psnr = false, m_ssim = false, m_ms = false, m_ansnr = false;
+    int m_exact = 0;                               // SSIM / MS-SSIM window sums and per-pixel terms as the reference's own expressions
     double psnr_peak = 255.0, psnr_max = 60.0;
     hipStream_t s_iqa = nullptr;
     hipEvent_t ev_iqa = nullptr;
@@ -204,7 +205,8 @@ void finish_metrics(const vmaf_hip_engine *e, const double *s, double *m)
         for (int i = 0; i < 5; ++i) {
             const double n = (double)((e->ms_w[i] - 10) * (e->ms_h[i] - 10));
             const float l = (float)(s[38 + 4 * i + 1] / n), c = (float)(s[38 + 4 * i + 2] / n), st = (float)(s[38 + 4 * i + 3] / n);
-            msssim *= std::pow(l, alphas[i]) * std::pow(c, betas[i]) * std::pow(st, gammas[i]);
+            // C's pow(): the float arguments widen to double (std::pow(float, float) would be powf, 4e-8 off in the score)
+            msssim *= std::pow((double)l, (double)alphas[i]) * std::pow((double)c, (double)betas[i]) * std::pow((double)st, (double)gammas[i]);
         }
         m[2] = msssim;
     }
@@ -344,17 +346,17 @@ int enqueue_batch(vmaf_hip_engine *e, const void *in_ref, const void *in_dis, in
             } else if (rs != e->w || fs != (size_t)e->w * e->h) {
                 return fail("ssim at decimation factor 1 needs dense input planes");
             }
-            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, 0, e->partials + e->part_off_ssim, nullptr, q));
+            HIP_TRY(vk_launch_ssim_stat(sr, sd, e->ssim_w, e->ssim_h, nframes, 0, e->m_exact, e->partials + e->part_off_ssim, nullptr, q));
         }
         if (e->m_ms) {
             if (rs != e->w || fs != (size_t)e->w * e->h) return fail("ms_ssim needs dense input planes");
             const float *cr0 = d_ref, *cd0 = d_dis;
             for (int i = 0; i < 5; ++i) {
-                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, i < 4 ? 1 : 0, e->partials + e->part_off_ms[i],   // ms_ssim.c:62-64: alpha = 0 below the last level
+                HIP_TRY(vk_launch_ssim_stat(cr0, cd0, e->ms_w[i], e->ms_h[i], nframes, i < 4 ? 1 : 0, e->m_exact, e->partials + e->part_off_ms[i],   // ms_ssim.c:62-64: alpha = 0 below the last level
                                             i == 0 && psnr_fused ? e->partials + e->part_off_psnr : nullptr, q));
                 if (i < 4) {
                     HIP_TRY(vk_launch_lpf_decimate(cr0, cd0, (size_t)e->ms_w[i] * e->ms_h[i], e->ms_w[i], e->ms_w[i], e->ms_h[i],
-                                                   e->ms_ref[i + 1], e->ms_dis[i + 1], e->ms_w[i + 1], e->ms_h[i + 1], nframes, q));
+                                                   e->ms_ref[i + 1], e->ms_dis[i + 1], e->ms_w[i + 1], e->ms_h[i + 1], nframes, e->m_exact, q));
                     cr0 = e->ms_ref[i + 1]; cd0 = e->ms_dis[i + 1];
                 }
             }
@@ -708,6 +710,14 @@ static int enable_metrics_impl(vmaf_hip_engine *e, int do_psnr, int do_ssim, int
     e->m_psnr = do_psnr != 0; e->m_ssim = do_ssim != 0; e->m_ms = do_ms_ssim != 0; e->m_ansnr = do_ansnr != 0;
     e->psnr_peak = ten_bit ? 255.75 : 255.0;                           // combo.c:171-186
     e->psnr_max = ten_bit ? 72.0 : 60.0;
+    return 0;
+}
+
+int vmaf_hip_engine_set_metrics_exact(vmaf_hip_engine *e, int exact)
+{
+    if (!e) return fail("null engine");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
+    e->m_exact = exact ? 1 : 0;
     return 0;
 }
 

@@ -59,13 +59,14 @@ hipError_t vk_launch_box_decimate(const float *src, size_t src_frame_stride, int
                                   int sw, int sh, int nframes, hipStream_t s);
 hipError_t vk_launch_box_decimate_pair(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h, int f,
                                        float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s);
+// exact: the reference's own expression for every window sum (float product, widened, added) instead of v_fma_f64
 hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h,
-                                  float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s);
+                                  float *oref, float *odis, int sw, int sh, int nframes, int exact, hipStream_t s);
 int vk_ansnr_tiles(int w, int h);
 hipError_t vk_launch_ansnr(const float *ref, const float *dis, size_t frame_stride, int row_stride, int w, int h, int nframes,
                            double *partial, hipStream_t s);
 // cs_only: only the contrast and structure sums (MS-SSIM levels whose luminance exponent is 0)
-hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, double *partial,
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, int exact, double *partial,
                                double *psnr_partial, hipStream_t s);
 hipError_t vk_launch_reduce(const double *partial, const vk_reduce_table *tab, int nframes, double *sums, hipStream_t s);
 hipError_t vk_launch_svm(const double *sv, const double *coef, int n_sv, int dim, double gamma, double rho, const double *x,

@@ -1442,6 +1442,9 @@ static_assert(LPF_TH * (LPF_TW / LPF_OPT) == 256 && LPF_IW % 8 == 0 && LPF_NW <=
 // product rounded to float, the sum kept in double, the result stored as float.  As in ssim_taps the terms enter the double
 // sum through v_fma_f64 (exact products; see there); a thread forms four neighbouring outputs of a row from one 16-sample
 // window per kernel row (widened once) instead of 9 samples per output.
+// EXACT: the reference's own expression - every product rounded to float before it is widened and added (three
+// instructions per tap instead of one); vmaf_hip_engine_set_metrics_exact.
+template <bool EXACT>
 __global__ __launch_bounds__(256, 4) void lpf_decimate_kernel(const float *__restrict__ ref, const float *__restrict__ dis,
                                                            size_t src_frame_stride, int src_row_stride, int w, int h,
                                                            float *__restrict__ oref, float *__restrict__ odis, int sw, int sh)
@@ -1504,7 +1507,10 @@ __global__ __launch_bounds__(256, 4) void lpf_decimate_kernel(const float *__res
 #pragma unroll
         for (int u = 0; u < 9; ++u)
 #pragma unroll
-            for (int o = 0; o < LPF_OPT; ++o) sum[o] = __builtin_fma(win[2 * o + u], kLpf9D[v * 9 + u], sum[o]);
+            for (int o = 0; o < LPF_OPT; ++o) {
+                if (EXACT) sum[o] = sum[o] + (double)((float)win[2 * o + u] * (float)kLpf9D[v * 9 + u]);   // iqa/convolve.c:262
+                else sum[o] = __builtin_fma(win[2 * o + u], kLpf9D[v * 9 + u], sum[o]);
+            }
     }
 #pragma unroll
     for (int o = 0; o < LPF_OPT; ++o)
@@ -1531,13 +1537,18 @@ static_assert(SS_IH * (SS_TW / SS_SEG) <= 256 && SS_TW * (SS_TH / SS_VR) == 256,
 __device__ constexpr double kSsimWinD[11] = { (double)0.001028f, (double)0.007599f, (double)0.036001f, (double)0.109361f, (double)0.213006f,
                                               (double)0.266012f, (double)0.213006f, (double)0.109361f, (double)0.036001f, (double)0.007599f,
                                               (double)0.001028f };
-template <int NOUT> __device__ __forceinline__ void ssim_taps(const double *win, float *out)
+// EXACT = the reference's expression itself: sum += img * k with the float product (iqa/convolve.c:129, :144); the window
+// holds samples that are floats widened to double, so narrowing them again is exact.
+template <int NOUT, bool EXACT> __device__ __forceinline__ void ssim_taps(const double *win, float *out)
 {
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) sum = __builtin_fma(win[o + k], kSsimWinD[k], sum);
+        for (int k = 0; k < 11; ++k) {
+            if (EXACT) sum = sum + (double)((float)win[o + k] * (float)kSsimWinD[k]);
+            else sum = __builtin_fma(win[o + k], kSsimWinD[k], sum);
+        }
         out[o] = (float)sum;
     }
 }
@@ -1576,7 +1587,9 @@ __device__ __forceinline__ double sqrt_of_float(float x)
 // planes again: 0.36 ms per 120 frames of 1080p).  A workgroup adds the pixels of its own 32 x 48 rectangle; the tiles
 // cover the valid area (w - 10) x (h - 10) only, so the last tile of a row / column also takes the up to 10 columns / rows
 // behind its rectangle, which its staged halo holds.
-template <bool CS_ONLY, bool PSNR>
+// EXACT: the window sums and the per-pixel sqrt / divisions as the reference's expressions (IEEE double sqrt and division
+// instead of the hardware estimates + Newton steps) - per-pixel l, c, s bit-identical to iqa/ssim_tools.c.
+template <bool CS_ONLY, bool PSNR, bool EXACT>
 __global__ __launch_bounds__(256, 3) void ssim_stat_kernel(const float *__restrict__ ref, const float *__restrict__ cmp, int w, int h,
                                                         double *__restrict__ partial, double *__restrict__ psnr_partial)
 {
@@ -1646,7 +1659,7 @@ __global__ __launch_bounds__(256, 3) void ssim_stat_kernel(const float *__restri
 #pragma unroll
             for (int k = 0; k < SS_SEG + 10; ++k)
                 t[k] = (double)(q == 0 ? a[k] : q == 1 ? b[k] : q == 2 ? a[k] * a[k] : q == 3 ? b[k] * b[k] : a[k] * b[k]);
-            ssim_taps<SS_SEG>(t, o);
+            ssim_taps<SS_SEG, EXACT>(t, o);
             float4 *dst = reinterpret_cast<float4 *>(&hc[q][row * SS_TW + seg * SS_SEG]);
             dst[0] = make_float4(o[0], o[1], o[2], o[3]);
             dst[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -1665,7 +1678,7 @@ __global__ __launch_bounds__(256, 3) void ssim_stat_kernel(const float *__restri
             double win[SS_VR + 10];
 #pragma unroll
             for (int k = 0; k < SS_VR + 10; ++k) win[k] = (double)hc[q][(oy0 + k) * SS_TW + ox];
-            ssim_taps<SS_VR>(win, m[q]);
+            ssim_taps<SS_VR, EXACT>(win, m[q]);
         }
 #pragma unroll
         for (int j = 0; j < SS_VR; ++j) {
@@ -1679,12 +1692,13 @@ __global__ __launch_bounds__(256, 3) void ssim_stat_kernel(const float *__restri
                 sb -= ref_mu * cmp_mu;
                 // the reference's sqrt() and divisions are IEEE double; the ones here agree with them to ~1e-14 relative
                 // (a per-pixel term of size <= 1 entering a mean: far below the 1e-7 of the window sums)
-                const double srsc = sqrt_of_float(rss * css);
-                const double c = (2.0 * srsc + C2) * rcp_newton((double)(rss + css + C2));
-                const double s_ = (sb + C2 / 2.0) * rcp_newton(srsc + C2 / 2.0);
+                const double srsc = EXACT ? __builtin_sqrt((double)(rss * css)) : sqrt_of_float(rss * css);
+                const double c = EXACT ? (2.0 * srsc + C2) / (double)(rss + css + C2) : (2.0 * srsc + C2) * rcp_newton((double)(rss + css + C2));
+                const double s_ = EXACT ? (sb + C2 / 2.0) / (srsc + C2 / 2.0) : (sb + C2 / 2.0) * rcp_newton(srsc + C2 / 2.0);
                 acc[2] += c; acc[3] += s_;
                 if (!CS_ONLY) {
-                    const double l = (2.0 * ref_mu * cmp_mu + C1) * rcp_newton((double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1));
+                    const double ld = (double)(ref_mu * ref_mu + cmp_mu * cmp_mu + C1);
+                    const double l = EXACT ? (2.0 * ref_mu * cmp_mu + C1) / ld : (2.0 * ref_mu * cmp_mu + C1) * rcp_newton(ld);
                     acc[0] += l * c * s_;
                     acc[1] += l;
                 }
@@ -1969,23 +1983,27 @@ hipError_t vk_launch_box_decimate_pair(const float *ref, const float *dis, size_
 }
 
 hipError_t vk_launch_lpf_decimate(const float *ref, const float *dis, size_t src_frame_stride, int src_row_stride, int w, int h,
-                                  float *oref, float *odis, int sw, int sh, int nframes, hipStream_t s)
+                                  float *oref, float *odis, int sw, int sh, int nframes, int exact, hipStream_t s)
 {
-    lpf_decimate_kernel<<<dim3((sw + LPF_TW - 1) / LPF_TW, (sh + LPF_TH - 1) / LPF_TH, 2 * nframes), 256, 0, s>>>(
-        ref, dis, src_frame_stride, src_row_stride, w, h, oref, odis, sw, sh);
+    const dim3 g((sw + LPF_TW - 1) / LPF_TW, (sh + LPF_TH - 1) / LPF_TH, 2 * nframes);
+    if (exact) lpf_decimate_kernel<true><<<g, 256, 0, s>>>(ref, dis, src_frame_stride, src_row_stride, w, h, oref, odis, sw, sh);
+    else lpf_decimate_kernel<false><<<g, 256, 0, s>>>(ref, dis, src_frame_stride, src_row_stride, w, h, oref, odis, sw, sh);
     return hipGetLastError();
 }
 
 // ref, cmp: dense planes [nframes][h][w]; partial receives vk_ssim_tiles(w, h) * 4 doubles per frame
 // psnr_partial: null, or vk_ssim_tiles(w, h) doubles per frame for the PSNR noise sums of the same planes (cs_only launches)
-hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, double *partial,
+hipError_t vk_launch_ssim_stat(const float *ref, const float *cmp, int w, int h, int nframes, int cs_only, int exact, double *partial,
                                double *psnr_partial, hipStream_t s)
 {
     const dim3 g((w - 10 + SS_TW - 1) / SS_TW, (h - 10 + SS_TH - 1) / SS_TH, nframes);
     if (psnr_partial && !cs_only) return hipErrorInvalidValue;      // the fused PSNR sum exists for MS-SSIM level 0 only
-    if (psnr_partial) ssim_stat_kernel<true, true><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, psnr_partial);
-    else if (cs_only) ssim_stat_kernel<true, false><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, nullptr);
-    else ssim_stat_kernel<false, false><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, nullptr);
+#define SSIM_STAT(EX)                                                                                             \
+    if (psnr_partial) ssim_stat_kernel<true, true, EX><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, psnr_partial);  \
+    else if (cs_only) ssim_stat_kernel<true, false, EX><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, nullptr);      \
+    else ssim_stat_kernel<false, false, EX><<<g, 256, 0, s>>>(ref, cmp, w, h, partial, nullptr)
+    if (exact) { SSIM_STAT(true); } else { SSIM_STAT(false); }
+#undef SSIM_STAT
     return hipGetLastError();
 }
 
