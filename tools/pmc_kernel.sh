@@ -9,7 +9,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 export VMAF_HIP_SERIAL=1
-timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pmc" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 "$@" > "$out/pmc.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pmc" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --steps 2 --warmup 1 "$@" > "$out/pmc.log" 2>&1
 cd "$root"
 python3 - "$out" <<'PY'
 import csv, glob, re, sys, collections

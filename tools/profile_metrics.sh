@@ -8,7 +8,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 export VMAF_HIP_SERIAL=1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_metrics" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --metrics --steps 6 > "$out/stats_metrics.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_metrics" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --metrics --steps 6 > "$out/stats_metrics.log" 2>&1
 cd "$root"
 python3 - "$out" <<'PY'
 import csv, glob, re, sys

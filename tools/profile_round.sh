@@ -15,16 +15,16 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 timeout -k 10 300 python3 -u bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end > "$out/stats.log" 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 > "$out/pmc_fetch.log" 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 > "$out/pmc_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 > "$out/stats.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --steps 2 --warmup 1 > "$out/pmc_fetch.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --steps 2 --warmup 1 > "$out/pmc_write.log" 2>&1
 # 4. VALU / LDS issue counters and exclusive kernel durations, one stream (VMAF_HIP_SERIAL=1)
 export VMAF_HIP_SERIAL=1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_valu" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 > "$out/pmc_valu.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_serial" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --steps 60 --warmup 10 > "$out/stats_serial.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_valu" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --steps 2 --warmup 1 > "$out/pmc_valu.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_serial" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --steps 60 --warmup 10 > "$out/stats_serial.log" 2>&1
 # 5. the optional metrics (PSNR / SSIM / MS-SSIM) next to the features, one stream: exclusive durations of their kernels
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_metrics" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --metrics --steps 30 --warmup 10 > "$out/stats_metrics.log" 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_metrics" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --metrics --steps 3 --warmup 2 > "$out/pmc_metrics.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_metrics" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --metrics --steps 30 --warmup 10 > "$out/stats_metrics.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_metrics" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --metrics --steps 3 --warmup 2 > "$out/pmc_metrics.log" 2>&1
 unset VMAF_HIP_SERIAL
 cd "$root"
 tail -1 "$out/bench.json"

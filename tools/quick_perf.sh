@@ -6,7 +6,7 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-timeout -k 10 300 python3 -u bench.py --no-cpu-baseline --no-end-to-end --steps 100 "$@" > "$out/bench.json" 2> "$out/bench.err"
+timeout -k 10 300 python3 -u bench.py --no-cpu-baseline --no-end-to-end --min-seconds 0 --steps 100 "$@" > "$out/bench.json" 2> "$out/bench.err"
 python3 -c "
 import json,sys
 l=json.loads(open('$out/bench.json').read().strip().split('\n')[-1])

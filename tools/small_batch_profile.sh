@@ -8,7 +8,7 @@ cd /tmp
 for n in 6 12 30; do
   out=$root/gpurun_out/small_batch/n$n
   mkdir -p "$out"
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --distinct $n --repeat 1 --steps 200 --warmup 10 > "$out/log.txt" 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o vm -- python3 "$root/bench.py" --no-cpu-baseline --no-end-to-end --min-seconds 0 --distinct $n --repeat 1 --steps 200 --warmup 10 > "$out/log.txt" 2>&1
   python3 - "$out" $n <<'PY'
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]

@@ -112,11 +112,18 @@ def main():
     # the dominant kernel = VIF scale 0: vif_stat_wg_kernel<17, true, 1> at widths that are multiples of 240 (1080p, 4K),
     # else vif_stat_avx_kernel<17, true>
     # (third template argument 1 = the reference's AVX order, the default; 2 = the opt-in fused order of bench.py's fast_mode leg)
-    dom = [r for r in rows if r["kernel"] == "vif_stat_wg_kernel<17, true, 1>"] or [r for r in rows if r["kernel"].startswith("vif_stat_avx_kernel<17")]
+    # from round 3 on the kernels that read the picture carry its sample type: "unsigned char" = bench.py's default (raw
+    # 8-bit luma resident in HBM), "float" = the fp32 planes of its f32_input leg
+    input_kind = "raw"
+    dom = [r for r in rows if r["kernel"] == "vif_stat_wg_kernel<17, true, 1, unsigned char>"]
+    if not dom:
+        input_kind = "f32"
+        dom = [r for r in rows if r["kernel"] in ("vif_stat_wg_kernel<17, true, 1>", "vif_stat_wg_kernel<17, true, 1, float>")] or \
+            [r for r in rows if r["kernel"].startswith("vif_stat_avx_kernel<17")]
     if dom:
         valu = sum(cnt["SQ_INSTS_VALU"].get(r["kernel"], (0.0, 0))[0] for r in dom)
         json.dump({"source": f"profiles/{tag}_hbm_traffic.csv, profiles/{tag}_valu_counters.csv",
-                   "kernels": [r["kernel"] for r in dom], "frames_per_launch": frames, "width": 1920, "height": 1080,
+                   "kernels": [r["kernel"] for r in dom], "frames_per_launch": frames, "width": 1920, "height": 1080, "input": input_kind,
                    "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] for r in dom),
                    "valu_wave_insts_per_launch": int(valu),
                    "exclusive_us": round(sum(dur.get(r["kernel"], 0.0) for r in dom) / 1e3, 1),

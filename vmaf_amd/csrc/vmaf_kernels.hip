@@ -221,15 +221,20 @@ template <> __device__ __forceinline__ float load_px<unsigned short>(__amdgpu_bu
 }
 
 // ---------------------------------------------------------------- VIF statistic
-// feature/src/vif_tools.c:33-75
-__device__ __forceinline__ float log2f_approx(float x)
+// feature/src/vif_tools.c:33-75: exponent + degree-8 polynomial in (mantissa - 1), Horner form, every step a separately
+// rounded multiply and add.  Two steps of the reference's loop are dropped because they cannot change a bit:
+//   the first one, 0.0f * t + c8 (t = mantissa - 1 lies in [0, 1): the product is +0, the sum c8), and
+//   the last one's "+ 0.0f" (log2_poly_s[0] = 0): it could only turn a -0 product into +0, and the value goes straight
+//   into e + v, which gives the same result for either zero (e is an integer-valued float or +0, never -0).
+// POSITIVE: the caller guarantees x > 0 (the denominator's argument 1 + sigma1_sq / 2 >= 2), so the reference's two
+// special cases (x == 0 -> -inf, x < 0 -> NaN) need no test.
+template <bool POSITIVE = false> __device__ __forceinline__ float log2f_approx(float x)
 {
     const uint32_t u = __float_as_uint(x);
     const float mant = __uint_as_float((u & 0x007FFFFFu) | 0x3F800000u);
     const float e = (float)((int)((u & 0x7F800000u) >> 23) - 127);
     const float t = mant - 1.0f;
-    float v = 0.0f;
-    v = v * t + -0.012671635276421f;
+    float v = -0.012671635276421f;
     v = v * t + 0.064841182402670f;
     v = v * t + -0.157048836463065f;
     v = v * t + 0.257167726303123f;
@@ -237,10 +242,12 @@ __device__ __forceinline__ float log2f_approx(float x)
     v = v * t + 0.480131410397451f;
     v = v * t + -0.721314327952201f;
     v = v * t + 1.442694803896991f;
-    v = v * t + 0.0f;
+    v = v * t;
     float r = e + v;
-    r = (x == 0.0f) ? -INFINITY : r;
-    r = (x < 0.0f) ? __uint_as_float(0x7FC00000u) : r;
+    if (!POSITIVE) {
+        r = (x == 0.0f) ? -INFINITY : r;
+        r = (x < 0.0f) ? __uint_as_float(0x7FC00000u) : r;
+    }
     return r;
 }
 
@@ -265,7 +272,7 @@ __device__ __forceinline__ void vif_pixel(float mu1, float mu2, float xxf, float
         const float g = sv - s12 * s12;
         const float l = log2f_approx(sv / g);
         num = (s12 < 0.0f) ? 0.0f : l;
-        den = log2f_approx(1.0f + s1 / sigma_nsq);
+        den = log2f_approx<true>(1.0f + s1 / sigma_nsq);           // s1 >= 2 here: the argument is >= 2
     }
 }
 
