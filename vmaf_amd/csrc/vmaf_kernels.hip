@@ -1102,29 +1102,31 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
 constexpr int MO_TW = 60, MO_THREADS = 256;
 constexpr int MO_CW = MO_TW + 4;                             // staged columns x0-2 .. x0+61
 constexpr int MO_WAVES = MO_THREADS / 64;
-constexpr int MO_BH = 8;                                     // rows per wave
-constexpr int MO_TH = MO_BH * MO_WAVES;                      // rows per workgroup
-constexpr int MO_OPT = 8;                                    // outputs per lane, horizontal pass
 constexpr int MO_VP = MO_CW + 4;                             // LDS row pitch: successive rows start 4 banks apart
 constexpr int MO_CMAX = 8;                                   // longest chunk of frames (running sums in LDS)
-constexpr int MO_G = 4;                                      // frames per group of row chains: MO_G x 8 rows = 32 lanes at work
 constexpr int MO_AP = MO_TW + 1;                             // row pitch of the parked |differences|: odd, so that the 32 lanes of
                                                              // a chain step read 32 different banks
-static_assert(MO_CW == 64 && MO_BH * (MO_CW / MO_OPT) == 64, "lane maps");
+static_assert(MO_CW == 64, "one lane per staged column");
 
 // Per-wave state of one step (60 columns) of the march
-struct MotionStep {
+template <int OPT> struct MotionStep {
     int x0;
     bool vcol_avx, v_all_avx, h_all_avx;
-    float prev[MO_OPT], live[MO_OPT];
+    float prev[OPT], live[OPT];
 };
 
-template <int ORDER, typename T>
+// BH = rows per wave: 8 (lane = row x 8 strips of 8 outputs; chains of 4 frames) or, for launches that would otherwise have
+// too few waves (4K, short batches: the launch's parallelism is rows x frames / chunk, nothing else), 4 (lane = row x 16
+// strips of 4 outputs, the last strip idle; chains of 8 frames) - twice the waves, half the work per wave and iteration.
+template <int ORDER, typename T, int BH>
 __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict__ ref, size_t frame_stride_bytes, int row_stride_bytes,
                                                             int w, int h, int nframes, int chunk, int has_carry,
                                                             const float *__restrict__ carry_in, float *__restrict__ carry_out,
                                                             float *__restrict__ rowsum, size_t rowsum_stride)
 {
+    constexpr int MO_BH = BH, MO_OPT = BH, MO_G = 32 / BH, MO_TH = BH * MO_WAVES;
+    constexpr int SPR = 64 / BH;                                      // strips (lanes) per row in the horizontal pass
+    static_assert(BH == 8 || BH == 4, "rows per wave");
     __shared__ __attribute__((aligned(16))) float v_all[MO_WAVES][MO_BH * MO_VP];
     __shared__ float acc_all[MO_WAVES][MO_CMAX * MO_BH];
     __shared__ float ad_all[MO_WAVES][MO_G * MO_BH * MO_AP];
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
     const unsigned frame_bytes = (unsigned)h * (unsigned)row_stride_bytes;
     const unsigned char *ref_b = reinterpret_cast<const unsigned char *>(ref);
     // horizontal-pass identity
-    const int hr = lane >> 3, strip = lane & 7, ox0 = strip * MO_OPT;
+    const int hr = lane / SPR, strip = lane & (SPR - 1), ox0 = strip * MO_OPT;
     const int gy = vy0 + hr;
     const int hend = avx_hcol_end(w, 2);
 
@@ -1169,7 +1171,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
         if (++ld_f == f_end) { ld_f = f_first; ld_x0 += MO_TW; }
     };
 
-    MotionStep st;
+    MotionStep<MO_OPT> st;
     int f = f_first;
     st.x0 = 0;
     auto begin_step = [&]() {
@@ -1209,10 +1211,12 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
         float win[MO_OPT + 4];
         {
             const float4 *src = reinterpret_cast<const float4 *>(vb + hr * MO_VP + ox0);
-            const float4 a = src[0], b = src[1], c = (ox0 + 8 < MO_CW) ? src[2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            win[0] = a.x; win[1] = a.y; win[2] = a.z; win[3] = a.w;
-            win[4] = b.x; win[5] = b.y; win[6] = b.z; win[7] = b.w;
-            win[8] = c.x; win[9] = c.y; win[10] = c.z; win[11] = c.w;
+            // the last strip of a row reaches beyond the 64 staged columns: its outputs there are not the tile's (masked)
+#pragma unroll
+            for (int m = 0; m < (MO_OPT + 4) / 4; ++m) {
+                const float4 q = (ox0 + 4 * m < MO_CW) ? src[m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                win[4 * m] = q.x; win[4 * m + 1] = q.y; win[4 * m + 2] = q.z; win[4 * m + 3] = q.w;
+            }
         }
         const bool scored = f >= f_begin && (f > 0 || has_carry);
         float cur[MO_OPT], ad[MO_OPT];
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
             float *dst = adb + (slot * MO_BH + hr) * MO_AP + ox0;
 #pragma unroll
             for (int j = 0; j < MO_OPT; ++j)
-                if (j < 4 || strip < 7) dst[j] = ad[j];
+                if (ox0 + j < MO_TW) dst[j] = ad[j];
             if (slot == MO_G - 1 || f + 1 == f_end) {
                 // motion.c:50-55: accum_line += fabs(..) over the columns in order.  (The reference adds in double and
                 // rounds to float at every step; for one addition of two floats that is the fp32 sum: 53 >= 2*24 + 2.)
@@ -1274,7 +1278,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
 
     wave_lds_sync();
     for (int i = lane; i < (f_end - f_begin) * MO_BH; i += 64) {
-        const int fi = i >> 3, r = i & 7;
+        const int fi = i / MO_BH, r = i % MO_BH;
         if (vy0 + r < h) rowsum[(size_t)(f_begin + fi) * rowsum_stride + vy0 + r] = acc_s[i];
     }
 }
@@ -1913,31 +1917,39 @@ hipError_t vk_launch_adm_scale(int scale, int order, const void *ref, const void
 hipError_t vk_launch_motion(int order, const void *ref, int sample_bytes, size_t frame_stride_bytes, int row_stride_bytes, int w, int h,
                             int nframes, int has_carry, const float *carry_in, float *carry_out, double *partial, hipStream_t s)
 {
-    // wave = (band of 8 rows, chunk of frames), marching over the columns (motion_kernel): the picture's width is serial,
+    // wave = (band of 8 or 4 rows, chunk of frames), marching over the columns (motion_kernel): the picture's width is serial,
     // so the launch gets its parallelism from rows x chunks.  Every chunk pays one extra blur per step (of the frame before
-    // it): chunks as long as ~6000 waves allow.
+    // it), so chunks are not made shorter than 4 frames; narrower bands come first.
     static const int forced = getenv("VMAF_HIP_MOTION_CHUNK") ? atoi(getenv("VMAF_HIP_MOTION_CHUNK")) : 0;
-    const int nbands = (h + MO_TH - 1) / MO_TH, rows8 = (h + MO_BH - 1) / MO_BH;
-    int chunk = forced > 0 ? forced : (int)(((long long)nframes * rows8 + 3071) / 6144);
-    chunk = (chunk + MO_G - 1) / MO_G * MO_G;                      // whole groups of row chains
-    if (chunk < MO_G) chunk = MO_G;
+    static const int forced_bh = getenv("VMAF_HIP_MOTION_ROWS") ? atoi(getenv("VMAF_HIP_MOTION_ROWS")) : 0;
+    // 8 rows per wave and chunks of whole chain groups (4 frames) when that still gives ~3000 waves (1080p x 120 frames: 4050);
+    // otherwise 4 rows per wave (groups of 8 frames, chunks of 4)
+    const int rows8 = (h + 7) / 8;
+    int bh = (long long)rows8 * ((nframes + 3) / 4) >= 3000 ? 8 : 4;
+    if (forced_bh == 4 || forced_bh == 8) bh = forced_bh;
+    int chunk = forced > 0 ? forced : 4;
     if (chunk > MO_CMAX) chunk = MO_CMAX;
     if (chunk > nframes) chunk = nframes;
     const int nchunks = (nframes + chunk - 1) / chunk;
+    const int nbands = (h + bh * MO_WAVES - 1) / (bh * MO_WAVES);
     const dim3 g(nbands, nchunks, 1);
     const int tiles = vk_motion_tiles(w, h);
     float *rowsum = reinterpret_cast<float *>(partial + 1);
     const size_t rs_stride = (size_t)tiles * 2;
 #define MOTION_ARGS frame_stride_bytes, row_stride_bytes, w, h, nframes, chunk, has_carry, carry_in, carry_out, rowsum, rs_stride
-#define MOTION_T(T)                                                                                              \
-    if (order == ORDER_SCALAR) motion_kernel<ORDER_SCALAR, T><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS);  \
-    else if (order == ORDER_FMA) motion_kernel<ORDER_FMA, T><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS);   \
-    else motion_kernel<ORDER_AVX, T><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS)
+#define MOTION_OB(O, T, B) motion_kernel<O, T, B><<<g, MO_THREADS, 0, s>>>((const T *)ref, MOTION_ARGS)
+#define MOTION_O(O, T) do { if (bh == 8) MOTION_OB(O, T, 8); else MOTION_OB(O, T, 4); } while (0)
+#define MOTION_T(T)                                           \
+    if (order == ORDER_SCALAR) MOTION_O(ORDER_SCALAR, T);     \
+    else if (order == ORDER_FMA) MOTION_O(ORDER_FMA, T);      \
+    else MOTION_O(ORDER_AVX, T)
     if (sample_bytes == 4) { MOTION_T(float); }
     else if (sample_bytes == 1) { MOTION_T(unsigned char); }
     else if (sample_bytes == 2) { MOTION_T(unsigned short); }
     else return hipErrorInvalidValue;
 #undef MOTION_T
+#undef MOTION_O
+#undef MOTION_OB
 #undef MOTION_ARGS
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
