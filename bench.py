@@ -47,7 +47,8 @@ BITS = 8
 # are what fills the GPU in the small kernels of the path (VIF scales 2-3, ADM scales 1-3): 26.5k frames/s at 30 frames
 # per step, 28.0k at 60, 28.8k at 120.
 WORKLOADS = {"1080p": (1920, 1080, 8, 30, 4), "4k10": (3840, 2160, 10, 8, 6), "720p": (1280, 720, 8, 48, 4),
-             "576x324": (576, 324, 8, 48, 20)}      # configs[0], the reference's own CPU-runnable test clip size
+             "576x324": (576, 324, 8, 48, 20),      # configs[0], the reference's own CPU-runnable test clip size
+             "1080p10": (1920, 1080, 10, 30, 4), "4k": (3840, 2160, 8, 8, 6)}     # the other bit depth of each size
 MODEL = os.path.join(ROOT, "model", "vmaf_v0.6.1.pkl")
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PATH_BYTES_PER_PX = 26.5        # algorithmic bytes of the whole path per luma pixel

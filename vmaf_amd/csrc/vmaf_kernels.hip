@@ -219,6 +219,17 @@ template <> __device__ __forceinline__ float load_px<unsigned short>(__amdgpu_bu
 {
     return (float)__builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0) * 0.25f;
 }
+// The same sample after offset_image's -128 (combo.c:236-237, OPT_RANGE_PIXEL_OFFSET).  For 16-bit words the scaling and the
+// offset go into one fused multiply-add: px * 0.25 and px * 0.25 - 128 are both exactly representable (px < 2^16), so no
+// rounding happens in either form and the fused one gives the reference's bits with one instruction less.
+template <typename T> __device__ __forceinline__ float load_px_offset(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
+{
+    return load_px<T>(r, x, row_off_bytes) + -128.0f;
+}
+template <> __device__ __forceinline__ float load_px_offset<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
+{
+    return __builtin_fmaf((float)__builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0), 0.25f, -128.0f);
+}
 
 // ---------------------------------------------------------------- VIF statistic
 // feature/src/vif_tools.c:33-75: exponent + degree-8 polynomial in (mantissa - 1), Horner form, every step a separately
@@ -428,12 +439,8 @@ __device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int roff = mirror_idx(y0 - R + i, h) * row_stride * (int)sizeof(T);   // wave-uniform: SGPR
-                rv[i] = load_px<T>(br, gxc, roff);
-                dv[i] = load_px<T>(bd, gxc, roff);
-            }
-            if (OFFSET) {
-#pragma unroll
-                for (int i = 0; i < NW; ++i) { rv[i] = rv[i] + -128.0f; dv[i] = dv[i] + -128.0f; }   // offset_image, combo.c:236-237
+                rv[i] = OFFSET ? load_px_offset<T>(br, gxc, roff) : load_px<T>(br, gxc, roff);       // offset_image, combo.c:236-237
+                dv[i] = OFFSET ? load_px_offset<T>(bd, gxc, roff) : load_px<T>(bd, gxc, roff);
             }
             if (DFW > 0) {
                 // decimation, vertical pass at the even rows (y0 is even): output row y0 + 2i is window element R + 2i
@@ -649,12 +656,8 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int roff = mirror_idx(y0 - R + i, h) * row_stride * (int)sizeof(T);   // workgroup-uniform: SGPR
-            rv[i] = load_px<T>(br, gxc, roff);
-            dv[i] = load_px<T>(bd, gxc, roff);
-        }
-        if (OFFSET) {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) { rv[i] = rv[i] + -128.0f; dv[i] = dv[i] + -128.0f; }   // offset_image, combo.c:236-237
+            rv[i] = OFFSET ? load_px_offset<T>(br, gxc, roff) : load_px<T>(br, gxc, roff);           // offset_image, combo.c:236-237
+            dv[i] = OFFSET ? load_px_offset<T>(bd, gxc, roff) : load_px<T>(bd, gxc, roff);
         }
         if (DFW > 0) {
             // decimation, vertical pass at the even rows (y0 is even): output row y0 + 2i is window element R + 2i.
@@ -891,12 +894,8 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
 #pragma unroll
         for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
             const int roff = mirror_idx(iy0 + k, h) * in_row_stride * (int)sizeof(T);   // wave-uniform: SGPR
-            pr[k] = load_px<T>(br, xc, roff);
-            pd[k] = load_px<T>(bd, xc, roff);
-        }
-        if (OFFSET) {
-#pragma unroll
-            for (int k = 0; k < 2 * ADM_RPT + 2; ++k) { pr[k] = pr[k] + -128.0f; pd[k] = pd[k] + -128.0f; }   // offset_image, combo.c:236-237
+            pr[k] = OFFSET ? load_px_offset<T>(br, xc, roff) : load_px<T>(br, xc, roff);               // offset_image, combo.c:236-237
+            pd[k] = OFFSET ? load_px_offset<T>(bd, xc, roff) : load_px<T>(bd, xc, roff);
         }
         float4 *vdst = vbuf + (ty0 * 2 + (l & 1)) * ADM_VP + (l >> 1);
 #pragma unroll
@@ -1167,7 +1166,7 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
         const int xc = mirror_idx(min(ld_x0, w - 1) - 2 + lane, w);
         const auto b = sample_rsrc(reinterpret_cast<const T *>(ref_b + (size_t)ld_f * frame_stride_bytes), frame_bytes);
 #pragma unroll
-        for (int k = 0; k < MO_BH + 4; ++k) in[k] = load_px<T>(b, xc, roff[k]);
+        for (int k = 0; k < MO_BH + 4; ++k) in[k] = load_px_offset<T>(b, xc, roff[k]);           // offset_image, combo.c:236
         if (++ld_f == f_end) { ld_f = f_first; ld_x0 += MO_TW; }
     };
 
@@ -1195,8 +1194,6 @@ __global__ __launch_bounds__(MO_THREADS) void motion_kernel(const T *__restrict_
     // one iteration; returns false after the last one
     auto iterate = [&](float (&in)[MO_BH + 4]) -> bool {
         if (f == f_first) begin_step();
-#pragma unroll
-        for (int k = 0; k < MO_BH + 4; ++k) in[k] = in[k] + -128.0f;                  // offset_image, combo.c:236
         wave_lds_sync();                                                              // the previous iteration's reads stay before these writes
         if (ORDER != ORDER_AVX || st.v_all_avx) {
 #pragma unroll
