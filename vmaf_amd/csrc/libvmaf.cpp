@@ -304,8 +304,8 @@ struct ShardFailure { long frame; std::string msg; };
 // ahead of the GPU, this thread hands ready sets to the engine (at most two calls in flight) and frees a set when its
 // call has been collected - reading, the H2D copies and the kernels of different batches all overlap, and this thread's
 // enqueue time (~0.5 ms per batch) no longer adds to the reading time.  Writes atoms[start..stop).
-// Start-up order: the page-locked buffers first (that initialises the HIP runtime), then the engine is created on a helper
-// thread (device context, streams: ~18 ms) WHILE the reader stage already fetches the first batches.
+// Start-up order: the engine is created on a helper thread (runtime initialisation, device context, streams, the kernels'
+// code object: ~30 ms) WHILE this thread page-locks the buffers and the reader stage already fetches the first batches.
 constexpr int kRing = 4;
 
 void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar_order, const MetricFlags &mf, long start, long stop,
@@ -319,15 +319,6 @@ void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar
     const int ring = (int)std::min<long>(kRing, nb);
     EngineGuard guard;
     char *ref[kRing] = {}, *dis[kRing] = {};
-    for (int b = 0; b < ring; ++b) {
-        char **pp[2] = { &ref[b], &dis[b] };
-        for (auto p : pp) {
-            *p = (char *)vmaf_hip_host_alloc(plane * batch);
-            if (!*p) throw VmafException(vmaf_hip_last_error());
-            guard.pinned.push_back(*p);
-        }
-    }
-    trace("shard: page-locked buffers ready");
     vmaf_hip_engine *e = nullptr;
     std::string create_err;
     std::thread creator([&] {
@@ -337,6 +328,21 @@ void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar
             (mf.any() && (vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit) || vmaf_hip_engine_set_metrics_exact(e, scalar_order))))
             create_err = vmaf_hip_last_error();
     });
+    try {
+        for (int b = 0; b < ring; ++b) {
+            char **pp[2] = { &ref[b], &dis[b] };
+            for (auto p : pp) {
+                *p = (char *)vmaf_hip_host_alloc(plane * batch);
+                if (!*p) throw VmafException(vmaf_hip_last_error());
+                guard.pinned.push_back(*p);
+            }
+        }
+    } catch (...) {
+        creator.join();
+        if (e) guard.engines.push_back(e);
+        throw;
+    }
+    trace("shard: page-locked buffers ready");
 
     // ---- reader stage
     struct Ring {

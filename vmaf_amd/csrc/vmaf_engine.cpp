@@ -23,6 +23,7 @@
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include "../../include/vmaf_hip.h"
 #include "../../include/vmaf_hip_debug.h"
@@ -540,6 +541,13 @@ int vmaf_hip_engine_create(vmaf_hip_engine **out, int device, int width, int hei
     trace("create: device count known (runtime initialised)");
     HIP_TRY(hipSetDevice(device));
     trace("create: device set");
+    // the kernels' code object goes to the device on a helper thread while the streams are created here (otherwise the
+    // first launch loads it: ~10 ms in front of the first batch of a short run); joined on every way out
+    struct Preload {
+        std::thread t;
+        explicit Preload(int dev) : t([dev] { if (hipSetDevice(dev) == hipSuccess) (void)vk_preload(); trace("create: code object loaded"); }) {}
+        ~Preload() { t.join(); }
+    } preload(device);
 
     vmaf_hip_engine *e = new (std::nothrow) vmaf_hip_engine();
     if (!e) return fail("out of host memory");

@@ -32,6 +32,8 @@ extern "C" {
 int vk_vif_tiles(int w, int h);
 int vk_adm_tiles(int w, int h);     // w,h = INPUT size of the scale
 int vk_motion_tiles(int w, int h);
+// loads the kernels' code object onto the current device (otherwise the first launch does, ~10 ms)
+hipError_t vk_preload(void);
 
 // order: 0 = the reference's scalar tap order (disable_avx), 1 = its AVX order (default on x86), 2 = fused multiply-adds.
 // ref / dis at scale 0: the caller's picture, sample_bytes 4 = fp32 planes, 1 = 8-bit samples, 2 = little-endian 16-bit words

@@ -1846,6 +1846,15 @@ int vk_adm_tiles(int w, int h)
 // doubles per frame in the partial buffer: [0] the frame's SAD total (fp32 value), then its h row sums as packed floats
 int vk_motion_tiles(int w, int h) { (void)w; return 1 + (h + 1) / 2; }
 
+// The runtime loads a library's code object onto a device when the first of its kernels is launched there (or looked up):
+// ~10 ms for this library, on the launching thread.  An engine being created asks for it here, on a helper thread, while
+// its streams are set up - so that the first batch does not pay for it.  All kernels live in this one code object.
+hipError_t vk_preload(void)
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&reduce_kernel));
+}
+
 hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
                               int out_row_stride, hipStream_t s)
