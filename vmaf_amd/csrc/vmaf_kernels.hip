@@ -215,9 +215,18 @@ template <> __device__ __forceinline__ float load_px<unsigned char>(__amdgpu_buf
 {
     return (float)__builtin_amdgcn_raw_buffer_load_b8(r, x, row_off_bytes, 0);
 }
+// buffer_load_ushort zero-extends into the whole register, but the builtin's 16-bit type makes the compiler widen again
+// through an SDWA conversion (v_cvt_f32_u32_sdwa .. src0_sel:WORD_0); the plain conversion of the register is the same value
+__device__ __forceinline__ float load_u16_as_float(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
+{
+    const unsigned short s = __builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0);
+    float f;
+    asm("v_cvt_f32_u32_e32 %0, %1" : "=v"(f) : "v"(s));
+    return f;
+}
 template <> __device__ __forceinline__ float load_px<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
 {
-    return (float)__builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0) * 0.25f;
+    return load_u16_as_float(r, x, row_off_bytes) * 0.25f;
 }
 // The same sample after offset_image's -128 (combo.c:236-237, OPT_RANGE_PIXEL_OFFSET).  For 16-bit words the scaling and the
 // offset go into one fused multiply-add: px * 0.25 and px * 0.25 - 128 are both exactly representable (px < 2^16), so no
@@ -228,7 +237,7 @@ template <typename T> __device__ __forceinline__ float load_px_offset(__amdgpu_b
 }
 template <> __device__ __forceinline__ float load_px_offset<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
 {
-    return __builtin_fmaf((float)__builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0), 0.25f, -128.0f);
+    return __builtin_fmaf(load_u16_as_float(r, x, row_off_bytes), 0.25f, -128.0f);
 }
 
 // ---------------------------------------------------------------- VIF statistic
