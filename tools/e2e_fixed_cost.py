@@ -27,7 +27,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
                 f.write(one_r)
                 g.write(one_d)
         have = frames
-        for env in ({}, {"VMAF_HIP_READ_THREADS": "16"}, {"VMAF_HIP_DEVICES": "0,0"}, {"VMAF_HIP_DEVICES": "0,0", "VMAF_HIP_READ_THREADS": "16"}):
+        for env in ({}, {"VMAF_HIP_READ_THREADS": "16"}, {"VMAF_HIP_DEVICES": "0,0"}, {"VMAF_HIP_DEVICES": "0,0,0,0"}):
             best = 1e9
             for _ in range(2):
                 t0 = time.perf_counter()
