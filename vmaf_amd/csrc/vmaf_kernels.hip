@@ -887,6 +887,12 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
     // workgroup whose interior coefficients all lie outside the window (28 % of them at 1080p) therefore contributes
     // nothing but its LL band: it runs the low-pass halves of the two DWT passes and skips everything else.
     const bool in_window = cx0 < right && cx0 + ADM_TW > left && cy0 < bottom && cy0 + ADM_TH > top;   // workgroup-uniform
+    // A tile none of whose slots (halo included) lies on or beyond the picture's outermost coefficients, and none of whose
+    // pixel taps leaves the picture, needs no mirror rule anywhere (workgroup-uniform; most tiles): its rows and columns are
+    // consecutive and the halo slots of phase 3 have real neighbours.  The general path costs such a tile ~300 scalar and
+    // branch instructions per wave that decide nothing.
+    const bool inner_tile = cx0 >= 3 && cx0 + ADM_SW < bw - 1 && cy0 >= 3 && cy0 + ADM_SH < bh - 1 &&
+                            2 * cx0 - 3 + ADM_COLS <= w && 2 * (cy0 - 1 + ADM_SH) + 2 < h;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     if (in_window || ll_ref) {
 
@@ -894,17 +900,28 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
     {
         const int l = tid & (ADM_COLS - 1);
         const int half = __builtin_amdgcn_readfirstlane(tid >> 7);                // wave-uniform
-        const int xc = mirror_idx(2 * cx0 - 3 + l, w);                            // slot 0 = coefficient cx0-1, tap 0 = pixel 2(cx0-1)-1
         const int ty0 = half * ADM_RPT;
         const int iy0 = 2 * (cy0 - 1 + ty0) - 1;
         float pr[2 * ADM_RPT + 2], pd[2 * ADM_RPT + 2];
         const unsigned frame_bytes = (unsigned)h * (unsigned)in_row_stride * (unsigned)sizeof(T);
         const auto br = sample_rsrc(fr, frame_bytes), bd = sample_rsrc(fd, frame_bytes);
+        if (inner_tile) {
+            const int xc = 2 * cx0 - 3 + l;                                        // slot 0 = coefficient cx0-1, tap 0 = pixel 2(cx0-1)-1
+            const int roff0 = iy0 * in_row_stride * (int)sizeof(T);                // wave-uniform: SGPR
 #pragma unroll
-        for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
-            const int roff = mirror_idx(iy0 + k, h) * in_row_stride * (int)sizeof(T);   // wave-uniform: SGPR
-            pr[k] = OFFSET ? load_px_offset<T>(br, xc, roff) : load_px<T>(br, xc, roff);               // offset_image, combo.c:236-237
-            pd[k] = OFFSET ? load_px_offset<T>(bd, xc, roff) : load_px<T>(bd, xc, roff);
+            for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
+                const int roff = roff0 + k * in_row_stride * (int)sizeof(T);
+                pr[k] = OFFSET ? load_px_offset<T>(br, xc, roff) : load_px<T>(br, xc, roff);           // offset_image, combo.c:236-237
+                pd[k] = OFFSET ? load_px_offset<T>(bd, xc, roff) : load_px<T>(bd, xc, roff);
+            }
+        } else {
+            const int xc = mirror_idx(2 * cx0 - 3 + l, w);
+#pragma unroll
+            for (int k = 0; k < 2 * ADM_RPT + 2; ++k) {
+                const int roff = mirror_idx(iy0 + k, h) * in_row_stride * (int)sizeof(T);
+                pr[k] = OFFSET ? load_px_offset<T>(br, xc, roff) : load_px<T>(br, xc, roff);
+                pd[k] = OFFSET ? load_px_offset<T>(bd, xc, roff) : load_px<T>(bd, xc, roff);
+            }
         }
         float4 *vdst = vbuf + (ty0 * 2 + (l & 1)) * ADM_VP + (l >> 1);
 #pragma unroll
@@ -1011,7 +1028,15 @@ __global__ __launch_bounds__(ADM_THREADS, 4) void adm_scale_kernel(const T *__re
 
     // (1/30)|csf_a| planes; slots on the image edge also fill the halo slots that mirror onto them
     // (adm_tools.c:241-248: -1 -> 1, n -> n-1), so that phase 3 indexes its 3x3 window blindly
-    if (lane_on && cxr >= 0 && cxr < bw) {                               // slots outside the image own nothing
+    if (inner_tile) {
+        if (lane_on) {
+#pragma unroll
+            for (int s = 0; s < ADM_SPT; ++s) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) absa[(b * ADM_SH + wv * ADM_SPT + s) * ADM_AW + tx] = p30[s][b];
+            }
+        }
+    } else if (lane_on && cxr >= 0 && cxr < bw) {                        // slots outside the image own nothing
         const int cols[3] = { tx, (cxr == 1 && tx == 2) ? 0 : -1, (cxr == bw - 1 && tx + 1 < ADM_AW) ? tx + 1 : -1 };
 #pragma unroll
         for (int s = 0; s < ADM_SPT; ++s) {
