@@ -12,6 +12,35 @@ template <> __device__ __forceinline__ float ld<float>(__amdgpu_buffer_rsrc_t r,
 template <> __device__ __forceinline__ float ld<unsigned char>(__amdgpu_buffer_rsrc_t r, int x, int roff) { return (float)__builtin_amdgcn_raw_buffer_load_b8(r, x, roff, 0); }
 template <> __device__ __forceinline__ float ld<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int roff) { return (float)__builtin_amdgcn_raw_buffer_load_b16(r, x * 2, roff, 0); }
 
+// FMT: typed buffer loads - the descriptor names the sample format (8 or 16 bit, USCALED) and the load path converts to float
+__device__ float llvm_amdgcn_raw_ptr_buffer_load_format_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.f32");
+template <typename T>
+__global__ __launch_bounds__(256, 4) void tile_read_fmt(const T *__restrict__ ref, const T *__restrict__ dis, int w, int h, float *__restrict__ out)
+{
+    constexpr int ROWS = 24;
+    const int ntx = w / 240;
+    const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    const int x0 = tx * 240 - 8, y0 = ty * 8 - 8;
+    int xc = x0 + (int)threadIdx.x;
+    xc = xc < 0 ? -xc : xc; xc = xc >= w ? 2 * w - xc - 1 : xc;
+    const size_t fo = (size_t)blockIdx.z * w * h;
+    const int word3 = 4 | (2 << 12) | ((sizeof(T) == 1 ? 1 : 2) << 15);        // dst_sel_x = X, num_format USCALED, data_format 8 / 16
+    const auto br = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(ref + fo), 0, (unsigned)(w * h * sizeof(T)), word3);
+    const auto bd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dis + fo), 0, (unsigned)(w * h * sizeof(T)), word3);
+    float a[ROWS], b[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        int y = y0 + i; y = y < 0 ? -y : y; y = y >= h ? 2 * h - y - 1 : y;
+        const int roff = y * w * (int)sizeof(T);
+        a[i] = llvm_amdgcn_raw_ptr_buffer_load_format_f32(br, xc * (int)sizeof(T), roff, 0);
+        b[i] = llvm_amdgcn_raw_ptr_buffer_load_format_f32(bd, xc * (int)sizeof(T), roff, 0);
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) acc += a[i] * b[i];
+    if (acc == 12345.678f) out[blockIdx.x] = acc;
+}
+
 // PAIR: 16-bit samples fetched as the aligned dword that holds the lane's sample (two lanes share one), half picked by shift
 template <typename T, int ROWS, bool PAIR>
 __global__ __launch_bounds__(256, 4) void tile_read(const T *__restrict__ ref, const T *__restrict__ dis, int w, int h, float *__restrict__ out)
@@ -69,6 +98,9 @@ int main()
         double t8 = time_ms([&] { tile_read<unsigned char, 24, false><<<g, 256>>>((const unsigned char *)ref, (const unsigned char *)dis, w, h, out); }, 20);
         double t16 = time_ms([&] { tile_read<unsigned short, 24, false><<<g, 256>>>((const unsigned short *)ref, (const unsigned short *)dis, w, h, out); }, 20);
         double t16p = time_ms([&] { tile_read<unsigned short, 24, true><<<g, 256>>>((const unsigned short *)ref, (const unsigned short *)dis, w, h, out); }, 20);
+        double t8f = time_ms([&] { tile_read_fmt<unsigned char><<<g, 256>>>((const unsigned char *)ref, (const unsigned char *)dis, w, h, out); }, 20);
+        double t16f = time_ms([&] { tile_read_fmt<unsigned short><<<g, 256>>>((const unsigned short *)ref, (const unsigned short *)dis, w, h, out); }, 20);
+        printf("typed (format) loads, conversion in the load path: u8 %.1f us, u16 %.1f us\n", t8f * 1e3, t16f * 1e3);
         double t32 = time_ms([&] { tile_read<float, 24, false><<<g, 256>>>((const float *)ref, (const float *)dis, w, h, out); }, 20);
         printf("24 rows x 2 planes per thread, 1920x1080 x %d frames: u8 %.1f us, u16 %.1f us, u16 as dword pairs %.1f us, f32 %.1f us\n", frames, t8 * 1e3, t16 * 1e3, t16p * 1e3, t32 * 1e3);
     }

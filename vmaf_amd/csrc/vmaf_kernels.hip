@@ -29,6 +29,10 @@
 #include <stdlib.h>
 #include "vmaf_kernels.h"
 
+// typed buffer load (buffer_load_format_x): the LLVM intrinsic bound by name, see load_px below
+__device__ float llvm_amdgcn_raw_ptr_buffer_load_format_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.f32");
+
 namespace {
 
 // ---------------------------------------------------------------- tables
@@ -202,9 +206,18 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voffset_
 //   unsigned short (float)px / 4.0 = px * 0.25f    read_image_w2s (little-endian words, no masking to 10 bits); exact
 // The kernels that read the picture (VIF scale 0, ADM scale 0, motion) are templated on the sample type, so raw 8/16-bit
 // luma is widened in the load and never exists as fp32 planes in HBM.  x = sample index in the row, row offset in bytes.
+// Integer samples come through TYPED buffer loads: the frame's descriptor names their format (8 or 16 bit, USCALED =
+// unsigned integer -> float, exact) and the load path itself delivers (float)px - no conversion instruction in the kernel
+// (buffer_load_format_x issues at the rate of buffer_load_ubyte / _ushort / _dword: tools/subdword_ubench.hip).  clang has
+// no builtin for it; llvm_amdgcn_raw_ptr_buffer_load_format_f32 (declared above the namespace) binds the LLVM intrinsic by
+// name, so that the compiler still tracks the load (s_waitcnt vmcnt) as it does for its own builtins.
+// descriptor word 3 (gfx9 layout): DST_SEL_X [2:0] = 4 (X), NUM_FORMAT [14:12] = 2 (USCALED), DATA_FORMAT [18:15] = 1 (8) / 2 (16) / 4 (32)
+template <typename T> __device__ __forceinline__ constexpr int sample_rsrc_flags() { return 0x00020000; }
+template <> __device__ __forceinline__ constexpr int sample_rsrc_flags<unsigned char>() { return 4 | (2 << 12) | (1 << 15); }
+template <> __device__ __forceinline__ constexpr int sample_rsrc_flags<unsigned short>() { return 4 | (2 << 12) | (2 << 15); }
 template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t sample_rsrc(const T *base, unsigned bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, bytes, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, bytes, sample_rsrc_flags<T>());
 }
 template <typename T> __device__ __forceinline__ float load_px(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes);
 template <> __device__ __forceinline__ float load_px<float>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
@@ -213,20 +226,11 @@ template <> __device__ __forceinline__ float load_px<float>(__amdgpu_buffer_rsrc
 }
 template <> __device__ __forceinline__ float load_px<unsigned char>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
 {
-    return (float)__builtin_amdgcn_raw_buffer_load_b8(r, x, row_off_bytes, 0);
-}
-// buffer_load_ushort zero-extends into the whole register, but the builtin's 16-bit type makes the compiler widen again
-// through an SDWA conversion (v_cvt_f32_u32_sdwa .. src0_sel:WORD_0); the plain conversion of the register is the same value
-__device__ __forceinline__ float load_u16_as_float(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
-{
-    const unsigned short s = __builtin_amdgcn_raw_buffer_load_b16(r, x * 2, row_off_bytes, 0);
-    float f;
-    asm("v_cvt_f32_u32_e32 %0, %1" : "=v"(f) : "v"(s));
-    return f;
+    return llvm_amdgcn_raw_ptr_buffer_load_format_f32(r, x, row_off_bytes, 0);
 }
 template <> __device__ __forceinline__ float load_px<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
 {
-    return load_u16_as_float(r, x, row_off_bytes) * 0.25f;
+    return llvm_amdgcn_raw_ptr_buffer_load_format_f32(r, x * 2, row_off_bytes, 0) * 0.25f;
 }
 // The same sample after offset_image's -128 (combo.c:236-237, OPT_RANGE_PIXEL_OFFSET).  For 16-bit words the scaling and the
 // offset go into one fused multiply-add: px * 0.25 and px * 0.25 - 128 are both exactly representable (px < 2^16), so no
@@ -237,7 +241,7 @@ template <typename T> __device__ __forceinline__ float load_px_offset(__amdgpu_b
 }
 template <> __device__ __forceinline__ float load_px_offset<unsigned short>(__amdgpu_buffer_rsrc_t r, int x, int row_off_bytes)
 {
-    return __builtin_fmaf(load_u16_as_float(r, x, row_off_bytes), 0.25f, -128.0f);
+    return __builtin_fmaf(llvm_amdgcn_raw_ptr_buffer_load_format_f32(r, x * 2, row_off_bytes, 0), 0.25f, -128.0f);
 }
 
 // ---------------------------------------------------------------- VIF statistic
