@@ -340,6 +340,37 @@ def test_raw_luma_device_pointers_and_errors():
         assert "bytes_per_sample" in vmaf_amd.binding._err(e.L)
 
 
+@pytest.mark.parametrize("bits,w,h,pad,skew", [(8, 256, 96, 13, 1), (8, 101, 75, 3, 3), (10, 248, 130, 6, 1), (8, 496, 288, 16, 5)])
+def test_raw_device_planes_with_padded_rows_and_unaligned_bases(bits, w, h, pad, skew):
+    """The raw device entry takes byte strides: rows padded by `pad` samples, frames by a few rows, and the first sample
+    `skew` samples into the allocation (an odd byte address for 8-bit input) - the typed buffer loads of VIF scale 0
+    (workgroup-wide and wave-private tiles), ADM scale 0 (inner and edge tiles) and motion must deliver the same samples as
+    from dense planes: atoms bit-identical."""
+    torch = pytest.importorskip("torch")
+    frames = 3
+    r, d = synth.make_clip(w, h, frames, bits=bits, seed=300 + w)
+    bps = r.dtype.itemsize
+    with vmaf_amd.Engine(w, h, max_batch=frames) as e:
+        want = e.extract_raw(r, d)
+    rs, fs = w + pad, (w + pad) * (h + 2)                          # in samples
+
+    def padded(a):
+        buf = np.full(skew + frames * fs, 77, dtype=a.dtype)
+        view = buf[skew:].reshape(frames, h + 2, w + pad)
+        view[:, :h, :w] = a
+        return buf
+    br, bd = padded(r), padded(d)
+    as_t = (lambda a: torch.from_numpy(a)) if bps == 1 else (lambda a: torch.from_numpy(a.view(np.int16)))
+    tr, td = as_t(br).cuda(), as_t(bd).cuda()
+    torch.cuda.synchronize()
+    out = np.zeros((frames, 20))
+    with vmaf_amd.Engine(w, h, max_batch=frames) as e:
+        rc = e.L.vmaf_hip_extract_device_raw(e._h, tr.data_ptr() + skew * bps, td.data_ptr() + skew * bps, bps, rs * bps, fs * bps,
+                                             frames, 0, out.ctypes.data_as(vmaf_amd.binding._dp))
+        assert rc == 0, vmaf_amd.binding._err(e.L)
+    assert np.array_equal(out, want)
+
+
 @pytest.mark.parametrize("bits,w,h", [(8, 576, 324), (8, 1280, 720), (10, 577, 325), (8, 200, 180), (8, 1920, 1080),
                                       (8, 1030, 520), (10, 1301, 1281), (8, 2050, 2062)])
 def test_psnr_ssim_ms_ssim_match_oracle(bits, w, h):
