@@ -396,14 +396,19 @@ def main():
             oa = np.zeros((K, B, 20))
             for i in range(args.warmup):
                 run_batch(engo, i > 0, scratch, raw=not raw_in)
+            engo.arm_timing()
             torch.cuda.synchronize()
             to0 = time.perf_counter()
             pipelined(engo, K, oa, raw=not raw_in)
             vmaf_amd.predict_from_atoms(oa.reshape(K * B, 20), MODEL, device=local_rank)
             torch.cuda.synchronize()
             to = time.perf_counter() - to0
+            o_ms = engo.last_kernel_ms(1)                            # the dominant kernel's launch of the last batch (HIP events)
+        o_bytes = (10.0 if raw_in else 2.0 * BPS + 2.0) * W * H * B   # this form's algorithmic bytes of that launch
         other = {"value": round(K * B / to, 2), "unit": "frames/sec", "ms_per_step": round(1e3 * to / K, 4),
                  "atoms_identical_to_headline": bool(np.array_equal(oa, atoms)),
+                 "roofline": ({"launch_ms": round(o_ms, 4), "algorithmic_bytes": int(o_bytes), "achieved": round(o_bytes / (o_ms * 1e-3) / 1e9, 1),
+                               "unit": "GB/s", "frac": round(o_bytes / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if o_ms > 0 else None),
                  "what": ("fp32 luma planes resident in HBM (the read_frame contract; the headline of rounds 1-2)" if raw_in else
                           f"raw uint{8 * BPS} luma resident in HBM, widened in the kernels' loads") + ", same loop and fusion, outside the timed region"}
     if rank == 0:
