@@ -213,6 +213,9 @@ def main():
                          "4 at 1080p = 120 frames per step; 1 = 30 frames per step)")
     ap.add_argument("--distinct", type=int, default=0,
                     help="use only the first N distinct synthetic frames (with --repeat 1: N frames per step; batch-size experiments)")
+    ap.add_argument("--sums-exact", action="store_true",
+                    help="VIF plane sums in vif_sum_s's own order (vmaf_hip_engine_set_sums_exact; what --disable-avx also selects): VIF "
+                         "atoms bit-identical to the reference's; not the headline workload")
     ap.add_argument("--metrics", action="store_true", help="also compute PSNR / SSIM / MS-SSIM per frame (not the headline workload)")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="beside the headline (never `value`): the same pipelined loop repeated three times for at least this long "
@@ -282,7 +285,7 @@ def main():
                 e.sync_oldest()
         e.sync()
 
-    eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order)
+    eng = vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order, sums_exact=args.sums_exact)
     if args.metrics:
         eng.L.vmaf_hip_engine_enable_metrics(eng._h, 1, 1, 1, 0)
     atoms = np.zeros((K, B, 20))
@@ -352,7 +355,7 @@ def main():
             else:
                 os.environ["VMAF_HIP_SERIAL"] = prev_serial
     fast = None
-    if rank == 0 and world == 1 and args.order == "avx" and not args.metrics:
+    if rank == 0 and world == 1 and args.order == "avx" and not args.metrics and not args.sums_exact:
         # beside the headline: the opt-in fused-multiply-add order (conv order 2, VMAF_HIP_FAST=1) on the same workload,
         # same pipelined loop + fusion, outside the timed region; and how far its numbers are from the headline run's
         with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order="fma") as engf:
@@ -390,7 +393,7 @@ def main():
                      "what": "the timed loop (two batches in flight + SVR fusion) repeated three times after the timed region"}
         del sa
     other = None
-    if rank == 0 and world == 1 and args.order == "avx" and not args.metrics:
+    if rank == 0 and world == 1 and args.order == "avx" and not args.metrics and not args.sums_exact:
         # beside the headline: the same loop with the luma resident in HBM in the other form (fp32 planes <-> raw samples)
         with vmaf_amd.Engine(W, H, max_batch=B, device=local_rank, order=args.order) as engo:
             oa = np.zeros((K, B, 20))
@@ -445,7 +448,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"synthetic {W}x{H} yuv420p {BITS}-bit ref/dis pair, vmaf_v0.6.1, " +
                                        (f"raw uint{8 * BPS} luma resident in HBM (widened to fp32 in the kernels' loads)" if raw_in else "fp32 luma resident in HBM") +
-                                       (" + psnr/ssim/ms_ssim" if args.metrics else ""),
+                                       (" + psnr/ssim/ms_ssim" if args.metrics else "") + (", VIF sums in the reference's order" if args.sums_exact else ""),
                            "frames_per_step_per_gpu": B, "distinct_frames": DISTINCT, "frames_total": frames,
                            "parallelism": f"frame-range x{world}, 1-frame motion halo" if world > 1 else "single GPU"},
                 "mean_vmaf": round(float(np.mean(vmaf)), 4), "roofline": roof}

@@ -77,6 +77,18 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e);
 int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order);
 
 /*
+ * Plane sums of VIF in the reference's own order (feature/src/vif_tools.c:161-179, vif_sum_s: one fp32 accumulator per row,
+ * columns left to right, then the row sums top to bottom in fp32).  By default the VIF kernels add their per-pixel num /
+ * den values - bit-identical to the reference's - in fp64 and reduce deterministically: the raw atoms vif_num_scaleN /
+ * vif_den_scaleN agree with the reference to ~1e-6 relative (they only ever feed ratios).  With exact = 1 the kernels also
+ * leave num and den as planes (the reference's own intermediate, vif.c:258-262; 8 bytes per pixel of the current scale in
+ * device memory, allocated here) and a second pass adds them as vif_sum_s does: the eight per-scale atoms and `vif` are then
+ * bit-identical to the reference's in the selected convolution order, for about a third more time per frame.  compute_vmaf
+ * sets it with disable_avx (the "most literal" mode).  Not while calls are in flight.
+ */
+int vmaf_hip_engine_set_sums_exact(vmaf_hip_engine *e, int exact);
+
+/*
  * Extract the 20 atoms of `nframes` CONSECUTIVE frames.  Replaces, per frame, the body of the
  * reference loop wrapper/src/combo.c:236-364:
  *   offset_image(-128) x2          (feature/src/common/file_io.c:177-198)

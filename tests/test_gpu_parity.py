@@ -340,6 +340,29 @@ def test_raw_luma_device_pointers_and_errors():
         assert "bytes_per_sample" in vmaf_amd.binding._err(e.L)
 
 
+@pytest.mark.parametrize("order", ["avx", "scalar"])
+@pytest.mark.parametrize("w,h,bits,frames", [(64, 48, 8, 3), (101, 75, 8, 2), (250, 130, 10, 2), (496, 288, 8, 2), (576, 324, 8, 3),
+                                             (1280, 720, 8, 1), (1920, 1080, 8, 2), (1928, 1090, 10, 1)])
+def test_exact_vif_sums_are_the_references_bit_for_bit(w, h, bits, frames, order):
+    """vmaf_hip_engine_set_sums_exact (what disable_avx selects in compute_vmaf): the per-pixel num / den values, already
+    bit-identical to the reference's, are added as vif_sum_s adds them (vif_tools.c:161-179: fp32 per row, then rows) - the
+    eight per-scale VIF atoms and `vif` equal the oracle's (= the compiled reference's, tests/test_oracle_vs_ref.py) exactly,
+    in both convolution orders, for both tile kernels, 8 and 10 bit.  The default path's fp64 sums must differ somewhere, or
+    the test would mean nothing; everything but VIF is unchanged by the switch."""
+    r, d = synth.make_clip(w, h, frames, bits=bits, seed=500 + w)
+    ref, dis = synth.to_luma_f32(r, bits), synth.to_luma_f32(d, bits)
+    want = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX if order == "avx" else oracle.ORDER_SCALAR)
+    with vmaf_amd.Engine(w, h, max_batch=2, order=order, sums_exact=True) as e:
+        got = e.extract_raw(r, d)
+    with vmaf_amd.Engine(w, h, max_batch=2, order=order) as e:
+        dflt = e.extract_raw(r, d)
+    assert np.array_equal(got[:, 11:20], want[:, 11:20]), (got[:, 11:20] - want[:, 11:20])
+    assert np.array_equal(got[:, :11], dflt[:, :11])
+    if w * h >= 250 * 130:
+        assert not np.array_equal(dflt[:, 11:19], want[:, 11:19])
+    _check(dflt, want, f"default sums {w}x{h}")
+
+
 @pytest.mark.parametrize("bits,w,h,pad,skew", [(8, 256, 96, 13, 1), (8, 101, 75, 3, 3), (10, 248, 130, 6, 1), (8, 496, 288, 16, 5)])
 def test_raw_device_planes_with_padded_rows_and_unaligned_bases(bits, w, h, pad, skew):
     """The raw device entry takes byte strides: rows padded by `pad` samples, frames by a few rows, and the first sample

@@ -63,6 +63,7 @@ def load_library():
     L.vmaf_hip_engine_enable_metrics.argtypes = [vp, i, i, i, i]
     L.vmaf_hip_engine_enable_ansnr.argtypes = [vp, i]
     L.vmaf_hip_engine_set_metrics_exact.argtypes = [vp, i]
+    L.vmaf_hip_engine_set_sums_exact.argtypes = [vp, i]
     L.vmaf_hip_engine_get_metrics.argtypes = [vp, _dp, i]
     L.vmaf_hip_engine_sync.argtypes = [vp]
     L.vmaf_hip_engine_sync_oldest.argtypes = [vp]
@@ -102,7 +103,7 @@ def device_count():
 class Engine:
     """One GPU, one frame geometry, one video's motion state (vmaf_hip_engine)."""
 
-    def __init__(self, width, height, max_batch=16, device=0, order="avx"):
+    def __init__(self, width, height, max_batch=16, device=0, order="avx", sums_exact=False):
         self.L = load_library()
         self.w, self.h, self.max_batch, self.device = width, height, max_batch, device
         h = C.c_void_p()
@@ -113,6 +114,9 @@ class Engine:
         self._metrics_on = False
         self.metrics = np.zeros((0, N_METRICS))      # of the frames of the last extract / extract_raw call
         if self.L.vmaf_hip_engine_set_conv_order(h, {"avx": 1, "scalar": 0, "fma": 2}[order]):
+            raise VmafHipError(_err(self.L))
+        # sums_exact: the VIF plane sums in vif_sum_s's own order (fp32 per row, then rows): VIF atoms bit-identical to the reference's
+        if sums_exact and self.L.vmaf_hip_engine_set_sums_exact(h, 1):
             raise VmafHipError(_err(self.L))
 
     def close(self):

@@ -119,7 +119,8 @@ void extract_atoms(const FrameSource &src, int w, int h, bool scalar_order, cons
         // the reference's two orders (disable_avx picks the scalar one); VMAF_HIP_FAST=1 opts into fused multiply-adds
         // instead: not bit-identical to either, inside the 1e-4 / 1e-3 tolerances, about a third faster
         static const bool fast = std::getenv("VMAF_HIP_FAST") && std::atoi(std::getenv("VMAF_HIP_FAST")) != 0;
-        if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1)) throw VmafException(vmaf_hip_last_error());
+        if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1) || vmaf_hip_engine_set_sums_exact(e, scalar_order))
+            throw VmafException(vmaf_hip_last_error());
         if (mf.any() && (vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit) || vmaf_hip_engine_set_metrics_exact(e, scalar_order)))
             throw VmafException(vmaf_hip_last_error());
         for (int b = 0; b < 2; ++b) {
@@ -324,7 +325,7 @@ void extract_shard(const FrameSource &src, int device, int w, int h, bool scalar
     std::thread creator([&] {
         if (vmaf_hip_engine_create(&e, device, w, h, batch)) { create_err = vmaf_hip_last_error(); return; }
         static const bool fast = std::getenv("VMAF_HIP_FAST") && std::atoi(std::getenv("VMAF_HIP_FAST")) != 0;
-        if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1) ||
+        if (vmaf_hip_engine_set_conv_order(e, scalar_order ? 0 : fast ? 2 : 1) || vmaf_hip_engine_set_sums_exact(e, scalar_order) ||
             (mf.any() && (vmaf_hip_engine_enable_metrics(e, mf.psnr, mf.ssim, mf.ms_ssim, mf.ten_bit) || vmaf_hip_engine_set_metrics_exact(e, scalar_order))))
             create_err = vmaf_hip_last_error();
     });

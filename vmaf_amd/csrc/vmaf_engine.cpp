@@ -83,7 +83,7 @@ struct Geometry {
     int w = 0, h = 0, max_batch = 0;
     int vw[4], vh[4];              // VIF plane size per scale
     int aw[5], ah[5];              // ADM input size per scale (index 4 = size of the last LL, unused)
-    size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_total;
+    size_t part_off_vif[4], part_off_adm[4], part_off_mot, part_off_vifx, part_total;   // vifx: 8 per frame, the VIF sums in vif_sum_s's order
     int tiles_vif[4], tiles_adm[4], tiles_mot;
     float rfac[8];
     int win[4][4];                 // ADM centre window per scale: left, top, right, bottom
@@ -94,6 +94,9 @@ struct FeatureBuffers {
     float *vif_ref[4] = {}, *vif_dis[4] = {};   // [1..3]
     float *adm_ref[4] = {}, *adm_dis[4] = {};   // [1..3] = LL of level 0..2
     double *partials = nullptr, *sums_dev = nullptr;
+    // set when the VIF plane sums are wanted in vif_sum_s's own order (vmaf_hip_engine_set_sums_exact): per-pixel num / den
+    // planes of the scale being worked on ([frame][2][h][w], sized for scale 0) and the row sums of such a pair of planes
+    float *vif_nd = nullptr, *vif_rowsum = nullptr;
 };
 
 struct vmaf_hip_engine : Geometry, FeatureBuffers {
@@ -232,6 +235,7 @@ void geometry_init(Geometry *g, int width, int height, int max_batch)
     for (int s = 0; s < 4; ++s) { g->tiles_vif[s] = vk_vif_tiles(g->vw[s], g->vh[s]); g->part_off_vif[s] = off; off += B * g->tiles_vif[s] * 2; }
     for (int s = 0; s < 4; ++s) { g->tiles_adm[s] = vk_adm_tiles(g->aw[s], g->ah[s]); g->part_off_adm[s] = off; off += B * g->tiles_adm[s] * 6; }
     g->tiles_mot = vk_motion_tiles(width, height); g->part_off_mot = off; off += B * g->tiles_mot;
+    g->part_off_vifx = off; off += B * 8;
     g->part_total = off;
 }
 
@@ -256,7 +260,9 @@ int launch_vif_scale(const Geometry *g, const FeatureBuffers *b, int order, int 
     const size_t nfs = sc < 3 ? (size_t)g->vw[sc + 1] * g->vh[sc + 1] : 0;
     const int nrs = sc < 3 ? g->vw[sc + 1] : 0;
     HIP_TRY(vk_launch_vif_stat(sc, order, c->ref, c->dis, c->sample, c->frame_stride, c->row_stride, g->vw[sc], g->vh[sc], nframes,
-                               b->partials + g->part_off_vif[sc], nr, nd, nfs, nrs, s));
+                               b->partials + g->part_off_vif[sc], nr, nd, nfs, nrs, b->vif_nd, s));
+    if (b->vif_nd)                                                 // vif.c:265-266 in vif_sum_s's order; the planes are reused by the next scale
+        HIP_TRY(vk_launch_vif_sums(b->vif_nd, g->vw[sc], g->vh[sc], nframes, b->vif_rowsum, b->partials + g->part_off_vifx, 8, sc, s));
     *c = { nr, nd, 4, nfs, nrs };
     return 0;
 }
@@ -275,11 +281,14 @@ int launch_adm_scale(const Geometry *g, const FeatureBuffers *b, int order, int 
 }
 
 // Sections [0..32] of the reduction table: VIF num/den x 4 scales, ADM 6 x 4 scales, motion.  Returns the next index.
-int fill_reduce_table(const Geometry *g, vk_reduce_table *tab)
+int fill_reduce_table(const Geometry *g, vk_reduce_table *tab, bool vif_sums_exact)
 {
     int q = 0;
     for (int sc = 0; sc < 4; ++sc)
-        for (int c = 0; c < 2; ++c) tab->d[q++] = { g->part_off_vif[sc], g->tiles_vif[sc], 2, c };
+        for (int c = 0; c < 2; ++c) {
+            if (vif_sums_exact) tab->d[q++] = { g->part_off_vifx, 1, 8, 2 * sc + c };   // one value per frame: vif_total_kernel's fp32 total
+            else tab->d[q++] = { g->part_off_vif[sc], g->tiles_vif[sc], 2, c };
+        }
     for (int sc = 0; sc < 4; ++sc)
         for (int c = 0; c < 6; ++c) tab->d[q++] = { g->part_off_adm[sc], g->tiles_adm[sc], 6, c };
     tab->d[q++] = { g->part_off_mot, 1, g->tiles_mot, 0 };    // one value per frame: motion_total_kernel's fp32 total
@@ -406,7 +415,7 @@ int enqueue_batch(vmaf_hip_engine *e, const void *in_ref, const void *in_dis, in
     HIP_TRY(hipStreamWaitEvent(s_join, e->ev_mot, 0));
     if (any_metric) HIP_TRY(hipStreamWaitEvent(s_join, e->ev_iqa, 0));
     vk_reduce_table tab;
-    int q = fill_reduce_table(e, &tab);
+    int q = fill_reduce_table(e, &tab, e->vif_nd != nullptr);
     tab.d[q++] = { e->part_off_psnr, e->m_psnr ? (psnr_fused ? e->tiles_ms[0] : e->tiles_psnr) : 0, 1, 0 };
     for (int c = 0; c < 4; ++c) tab.d[q++] = { e->part_off_ssim, e->m_ssim ? e->tiles_ssim : 0, 4, c };
     for (int i = 0; i < 5; ++i)
@@ -617,6 +626,7 @@ void vmaf_hip_engine_destroy(vmaf_hip_engine *e)
         (void)hipFree(e->raw_ref[i]); (void)hipFree(e->raw_dis[i]);
     }
     (void)hipFree(e->seed_buf);
+    (void)hipFree(e->vif_nd); (void)hipFree(e->vif_rowsum);
     (void)hipFree(e->ssim_ref); (void)hipFree(e->ssim_dis);
     for (int i = 1; i < 5; ++i) { (void)hipFree(e->ms_ref[i]); (void)hipFree(e->ms_dis[i]); }
     if (e->ev_iqa) (void)hipEventDestroy(e->ev_iqa);
@@ -726,6 +736,26 @@ int vmaf_hip_engine_set_metrics_exact(vmaf_hip_engine *e, int exact)
     if (!e) return fail("null engine");
     if (e->pend_count) return fail("a previous async extract has not been synchronised");
     e->m_exact = exact ? 1 : 0;
+    return 0;
+}
+
+int vmaf_hip_engine_set_sums_exact(vmaf_hip_engine *e, int exact)
+{
+    if (!e) return fail("null engine");
+    if (e->pend_count) return fail("a previous async extract has not been synchronised");
+    HIP_TRY(hipSetDevice(e->device));
+    if (exact && !e->vif_nd) {
+        const size_t B = (size_t)e->max_batch;
+        if (hipMalloc((void **)&e->vif_nd, B * 2 * e->w * e->h * sizeof(float)) != hipSuccess) { e->vif_nd = nullptr; return fail("hipMalloc(num / den planes) failed"); }
+        if (hipMalloc((void **)&e->vif_rowsum, B * 2 * e->h * sizeof(float)) != hipSuccess) {
+            (void)hipFree(e->vif_nd); e->vif_nd = nullptr; e->vif_rowsum = nullptr;
+            return fail("hipMalloc(row sums) failed");
+        }
+    } else if (!exact && e->vif_nd) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(e->vif_nd); (void)hipFree(e->vif_rowsum);
+        e->vif_nd = nullptr; e->vif_rowsum = nullptr;
+    }
     return 0;
 }
 
@@ -1097,7 +1127,7 @@ int vmaf_hip_extract_device_noalloc(int device, void *stream, const float *d_ref
         if (launch_adm_scale(&g, &L.b, conv_order, sc, &ac, nframes, s)) return 1;
     HIP_TRY(vk_launch_motion(conv_order, d_ref, 4, fs * 4, rs * 4, width, height, nframes, 0, L.carry, L.carry, L.b.partials + g.part_off_mot, s));
     vk_reduce_table tab;
-    int q = fill_reduce_table(&g, &tab);
+    int q = fill_reduce_table(&g, &tab, false);
     for (; q < VK_NSUMS; ++q) tab.d[q] = { 0, 0, 1, 0 };          // optional metrics: not computed here
     HIP_TRY(vk_launch_reduce(L.b.partials, &tab, nframes, L.b.sums_dev, s));
 

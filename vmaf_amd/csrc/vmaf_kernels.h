@@ -40,7 +40,11 @@ hipError_t vk_preload(void);
 // (value / 4.0), widened in the kernels' loads (file_io.c:112-116,159-163); strides in samples.  Scales 1-3: fp32 only.
 hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
-                              int out_row_stride, hipStream_t s);
+                              int out_row_stride, float *nd, hipStream_t s);
+// nd (null = off): per-pixel num / den planes [frame][2][h][w] written by the launch above; vk_launch_vif_sums adds them in
+// vif_sum_s's order (fp32 per row, then rows) -> out[frame * out_stride + 2 * scale + {0 num, 1 den}] as doubles.
+// rowsum: nframes * 2 * h floats of scratch
+hipError_t vk_launch_vif_sums(const float *nd, int w, int h, int nframes, float *rowsum, double *out, size_t out_stride, int scale, hipStream_t s);
 hipError_t vk_launch_adm_scale(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t in_frame_stride, int in_row_stride,
                                int w, int h, float *ll_ref, float *ll_dis, size_t ll_frame_stride, int ll_row_stride,
                                float rfac_hv, float rfac_d, int left, int top, int right, int bottom, int nframes,

@@ -366,8 +366,10 @@ __device__ __forceinline__ void border_tile_at(const BorderGeom &g, int b, int &
 // unsigned short for raw luma at scale 0 (widened in the loads, load_px)
 #define VIF_KERNEL_PARAMS const T *__restrict__ ref, const T *__restrict__ dis, size_t frame_stride, int row_stride, int w, int h, \
                           double *__restrict__ partial, float *__restrict__ oref, float *__restrict__ odis,                  \
-                          size_t out_frame_stride, int out_row_stride
-#define VIF_KERNEL_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+                          size_t out_frame_stride, int out_row_stride, float *__restrict__ nd
+// nd (null = off): the per-pixel num and den of vif_statistic as planes, [frame][num, den][h][w] - the reference's own
+// intermediate (vif.c:258-262), kept only when the caller wants the plane sums in vif_sum_s's order (vif_rowsum_kernel)
+#define VIF_KERNEL_ARGS ref, dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride, nd
 
 // ---------------------------------------------------------------- VIF
 // Fused VIF scale. Replaces, for one scale, vif.c:189-269: two mu filters, xx/yy/xy products, three filtered moments,
@@ -423,7 +425,7 @@ __device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile
                                               size_t frame_stride, int row_stride, int w, int h,
                                               double *__restrict__ partial,
                                               float *__restrict__ oref, float *__restrict__ odis,
-                                              size_t out_frame_stride, int out_row_stride)
+                                              size_t out_frame_stride, int out_row_stride, float *__restrict__ nd)
 {
     using G = VifWaveGeom<FW>;
     constexpr int R = G::R, VS = VWV_VS, DFW = G::DFW, RD = G::RD, DVW = G::DVW;
@@ -558,6 +560,11 @@ __device__ __forceinline__ void vif_wave_tile(float *smem, double *red, int tile
             // the interior tiles of ORDER_AVX lie inside the picture; elsewhere a tile may hang over its right / bottom edge
             const bool mine = (ORDER == ORDER_AVX && !BORDER) || (gx < w && gy < h);
             if (mine) { acc[0] += (double)n; acc[1] += (double)d; }
+            if (nd && mine) {                                 // (wave-uniform test first)
+                float *pn = nd + ((size_t)blockIdx.z * 2 * h + gy) * w + gx;
+                pn[0] = n;
+                pn[(size_t)h * w] = d;
+            }
         }
     }
     const size_t tile = (size_t)blockIdx.z * ntiles + tile_id;
@@ -800,6 +807,11 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
                 float n, d;
                 vif_pixel(ho[0][o], ho[1][o], ho[2][o], ho[3][o], ho[4][o], n, d);
                 acc[0] += (double)n; acc[1] += (double)d;
+                if (nd) {
+                    float *pn = nd + ((size_t)blockIdx.z * 2 * h + gy) * w + x0 + strip * VWG_HS + o;
+                    pn[0] = n;
+                    pn[(size_t)h * w] = d;
+                }
             }
         }
     }
@@ -807,9 +819,49 @@ __global__ __launch_bounds__(VIF_THREADS, VIF_WAVES_PER_SIMD) void vif_stat_wg_k
         float n, d;
         vif_pixel(he[0], he[1], he[2], he[3], he[4], n, d);
         acc[0] += (double)n; acc[1] += (double)d;
+        if (nd) {
+            float *pn = nd + ((size_t)blockIdx.z * 2 * h + y0 + erow) * w + x0 + ecol;
+            pn[0] = n;
+            pn[(size_t)h * w] = d;
+        }
     }
     const size_t tile = (size_t)blockIdx.z * ntiles + tile_id;
     block_reduce_store<2, VIF_THREADS / 64>(acc, red, partial + tile * 2);
+}
+
+// vif_sum_s (vif_tools.c:161-179) in its own order, for callers that want the plane sums to the reference's last bit: one
+// fp32 accumulator per row, columns left to right, then the row sums top to bottom in fp32.  The VIF kernels leave the
+// per-pixel num and den as planes (nd); lane = one row walks it 4 samples per load, 64 rows per wave side by side.
+__global__ __launch_bounds__(64) void vif_rowsum_kernel(const float *__restrict__ nd, int w, int h, float *__restrict__ rowsum)
+{
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= h) return;
+    const size_t plane = (size_t)blockIdx.z * 2 + blockIdx.y;         // [frame][num, den]
+    const float *p = nd + (plane * h + row) * w;
+    float acc = 0.0f;
+    int j = 0;
+    if ((w & 3) == 0) {
+        for (; j < w; j += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + j);
+            acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+        }
+    }
+    for (; j < w; ++j) acc = acc + p[j];
+    rowsum[plane * h + row] = acc;
+}
+// accum += accum_inner over the rows; one wave per (frame, num / den); the total goes to out[frame * out_stride + 2 * scale + plane]
+__global__ __launch_bounds__(64) void vif_total_kernel(const float *__restrict__ rowsum, int h, double *__restrict__ out, size_t out_stride, int scale)
+{
+    const int lane = threadIdx.x;
+    const size_t plane = (size_t)blockIdx.y * 2 + blockIdx.x;
+    const float *rs = rowsum + plane * h;
+    float acc = 0.0f;
+    for (int r0 = 0; r0 < h; r0 += 64) {
+        const float v = r0 + lane < h ? rs[r0 + lane] : 0.0f;        // + 0.0f beyond the last row: no change
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    }
+    if (lane == 0) out[(size_t)blockIdx.y * out_stride + 2 * scale + blockIdx.x] = (double)acc;
 }
 
 // ---------------------------------------------------------------- ADM
@@ -1895,7 +1947,7 @@ hipError_t vk_preload(void)
 
 hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void *dis, int sample_bytes, size_t frame_stride, int row_stride,
                               int w, int h, int nframes, double *partial, float *oref, float *odis, size_t out_frame_stride,
-                              int out_row_stride, hipStream_t s)
+                              int out_row_stride, float *nd, hipStream_t s)
 {
     static const int fw[4] = { 17, 9, 5, 3 };
     if (sample_bytes != 4 && scale != 0) return hipErrorInvalidValue;      // only the picture itself can be raw luma
@@ -1903,7 +1955,7 @@ hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void 
     const BorderGeom bg = border_geom(w, h, fw[scale] / 2, VIF_TW, VIF_TH);
     const int nb = bg.ntiles, ni = (bg.tx_r - 1) * (bg.ty_b - 1), nb_pad = ni > 0 ? (nb + 7) / 8 * 8 : nb;
     const dim3 gm(nb_pad + ni, 1, nframes);                   // border-frame tiles (padded) first, then the interior rectangle
-#define VIF_ARGS (const T *)ref, (const T *)dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride
+#define VIF_ARGS (const T *)ref, (const T *)dis, frame_stride, row_stride, w, h, partial, oref, odis, out_frame_stride, out_row_stride, nd
     const bool wg = vif_use_wg(w, h);
     const dim3 gw(wg ? vk_vif_tiles(w, h) : 1, 1, nframes);
 #define VIF_STAT(FW, OFF, TYPE)                                                                        \
@@ -1930,6 +1982,13 @@ hipError_t vk_launch_vif_stat(int scale, int order, const void *ref, const void 
     }
 #undef VIF_STAT
 #undef VIF_ARGS
+    return hipGetLastError();
+}
+
+hipError_t vk_launch_vif_sums(const float *nd, int w, int h, int nframes, float *rowsum, double *out, size_t out_stride, int scale, hipStream_t s)
+{
+    vif_rowsum_kernel<<<dim3((h + 63) / 64, 2, nframes), 64, 0, s>>>(nd, w, h, rowsum);
+    vif_total_kernel<<<dim3(2, nframes), 64, 0, s>>>(rowsum, h, out, out_stride, scale);
     return hipGetLastError();
 }
 
