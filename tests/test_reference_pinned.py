@@ -127,14 +127,18 @@ def test_engine_meets_the_reference_tests_pinned_values(case, order, model_path)
     pinned, 25757542.7 exact), while the kernels reduce in fp64 - they only feed ratios.  The oracle keeps the fp32 order
     and meets every place; here those sums are held to 1e-5 relative and ansnr / anpsnr (1.6e-5 relative in sig/noise =
     7e-5 dB) to one decimal place less.  The fused order is not bit-exact in the blur: its motion2 and VMAF are held to the
-    north-star tolerances."""
+    north-star tolerances.
+    Round 3: with vmaf_hip_engine_set_sums_exact (used here in the default order) the VIF sums are added in vif_sum_s's order too
+    and meet the pinned values to their places without slack, like motion; the ADM and ANSNR sums keep the fp64 reduction."""
     ref, dis = _clip(case)
-    with vmaf_amd.Engine(1920, 1080, max_batch=3, order=order) as e:
+    with vmaf_amd.Engine(1920, 1080, max_batch=3, order=order, sums_exact=(order == "avx")) as e:
         e.enable_metrics(psnr=False, ssim=True, ms_ssim=False)
         e.enable_ansnr()
         atoms = e.extract(ref, dis)
         m = e.metrics
-    exact = ("motion",) if order == "avx" else ()
+    # default order, with vmaf_hip_engine_set_sums_exact: motion and every VIF plane sum to the reference's own places, no slack
+    vif_sums = tuple(f"vif_{k}_scale{i}" for k in ("num", "den") for i in range(4)) + ("vif_num", "vif_den")
+    exact = ("motion",) + vif_sums if order == "avx" else ()
     _check_feature_tool(case, atoms, {"ansnr": m[:, 3].mean(), "anpsnr": m[:, 4].mean()}, sum_rtol=1e-5, one_place_less=("ansnr", "anpsnr"),
                         exact=exact)
     vm, _ = vmaf_amd.predict_from_atoms(atoms, model_path)
