@@ -256,7 +256,8 @@ FEATURE_TOOL = json.load(open(os.path.join(GOLD, "feature_tool.json")))
 def test_feature_tool_speaks_the_reference_grammar(name, tmp_path):
     """vmaf_amd/vmaf = the reference's per-feature tool `feature/vmaf app fmt ref dis w h` (vmaf_main.c): the same lines
     in the same order ("<atom>: <frame> <%f>", all.c:138-226) as the reference tool printed for the same files
-    (tests/golden/feature_tool.json), values within 1e-4 absolute / 2e-6 relative (plane sums are reduced in fp64 here)."""
+    (tests/golden/feature_tool.json), values within 1e-4 absolute / 2e-6 relative (the ADM / ANSNR plane sums are reduced in fp64 here); the vif_* and motion
+    lines - summed in the reference's own order - identical as text."""
     case = FEATURE_TOOL[name]
     kw = dict(ATOMS[case["clip"]]["params"])
     bits = kw.pop("bits", 8)
@@ -276,5 +277,7 @@ def test_feature_tool_speaks_the_reference_grammar(name, tmp_path):
         wk, wf, wv = w_.split()
         assert (gk, gf) == (wk, wf), (g, w_)
         assert abs(float(gv) - float(wv)) <= 1e-4 + 2e-6 * abs(float(wv)), (g, w_)
+        if gk.startswith("vif") or gk.startswith("motion"):            # summed in the reference's own order: the same text
+            assert g == w_, (g, w_)
     # usage errors: exit 2 (vmaf_main.c:161-176)
     assert subprocess.run([os.path.join(ROOT, "vmaf_amd", "vmaf"), "all"], capture_output=True, timeout=300).returncode == 2

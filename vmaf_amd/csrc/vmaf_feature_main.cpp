@@ -71,6 +71,9 @@ int main(int argc, char *argv[])
     const int batch = (int)std::min<size_t>(64, std::max<size_t>(4, ((size_t)64 << 20) / (n * bps)));
     vmaf_hip_engine *e = nullptr;
     if (vmaf_hip_engine_create(&e, 0, w, h, batch)) { std::printf("error: %s\n", vmaf_hip_last_error()); return 1; }
+    // this tool exists to print the raw atoms: the VIF plane sums in vif_sum_s's own order, so that its vif_* lines are the
+    // reference tool's to the last printed digit (motion always is)
+    if (vmaf_hip_engine_set_sums_exact(e, 1)) { std::printf("error: %s\n", vmaf_hip_last_error()); return 1; }
     if (do_ansnr && vmaf_hip_engine_enable_ansnr(e, bps == 2)) { std::printf("error: %s\n", vmaf_hip_last_error()); return 1; }
     char *rb = (char *)vmaf_hip_host_alloc(n * bps * batch), *db = (char *)vmaf_hip_host_alloc(n * bps * batch);
     std::vector<double> atoms((size_t)batch * VMAF_HIP_ATOMS), metrics((size_t)batch * VMAF_HIP_METRICS);
