@@ -83,7 +83,7 @@ int vmaf_hip_engine_set_conv_order(vmaf_hip_engine *e, int order);
  * vif_den_scaleN agree with the reference to ~1e-6 relative (they only ever feed ratios).  With exact = 1 the kernels also
  * leave num and den as planes (the reference's own intermediate, vif.c:258-262; 8 bytes per pixel of the current scale in
  * device memory, allocated here) and a second pass adds them as vif_sum_s does: the eight per-scale atoms and `vif` are then
- * bit-identical to the reference's in the selected convolution order, for about a third more time per frame.  compute_vmaf
+ * bit-identical to the reference's in the selected convolution order, for about a quarter more time per frame.  compute_vmaf
  * sets it with disable_avx (the "most literal" mode).  Not while calls are in flight.
  */
 int vmaf_hip_engine_set_sums_exact(vmaf_hip_engine *e, int exact);

@@ -841,6 +841,14 @@ __global__ __launch_bounds__(64) void vif_rowsum_kernel(const float *__restrict_
     float acc = 0.0f;
     int j = 0;
     if ((w & 3) == 0) {
+        // eight loads in flight before the first of their 32 additions: the chain waits for memory once per 32 samples
+        for (; j + 32 <= w; j += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(p + j + 4 * k);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc = acc + v[k].x; acc = acc + v[k].y; acc = acc + v[k].z; acc = acc + v[k].w; }
+        }
         for (; j < w; j += 4) {
             const float4 v = *reinterpret_cast<const float4 *>(p + j);
             acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
