@@ -2,7 +2,8 @@
 """One-off randomized parity sweep on the GPU box: random frame sizes (incl. sizes around the tile pitches of the
 kernels: 48x32 and 240x8 VIF, 61x14 ADM coefficients, 60x32 motion), both summation orders, against the CPU oracle.
     python tools/fuzz_parity.py [cases=80] [seed=1]
-Prints the worst relative atom error and the worst absolute feature error; exits 1 on a tolerance breach."""
+Prints the worst relative atom error and the worst absolute feature error; exits 1 on a tolerance breach, or when the motion
+atom (always) or the VIF atoms (engine with vmaf_hip_engine_set_sums_exact) are not bit-equal to the oracle's."""
 import os
 import sys
 
@@ -34,6 +35,12 @@ def main():
         want = oracle.clip_atoms(ref, dis, oracle.ORDER_AVX if order == "avx" else oracle.ORDER_SCALAR)
         with vmaf_amd.Engine(w, h, max_batch=2, order=order) as e:
             got = e.extract_raw(r, d)
+        with vmaf_amd.Engine(w, h, max_batch=2, order=order, sums_exact=True) as e:
+            lit = e.extract_raw(r, d)
+        # motion always, and with the VIF sums in vif_sum_s's order all nine VIF atoms: the reference's bits
+        if not (np.array_equal(got[:, 10], want[:, 10]) and np.array_equal(lit[:, 10:20], want[:, 10:20]) and np.array_equal(lit[:, :10], got[:, :10])):
+            bad += 1
+            print(f"NOT BIT-EQUAL {w}x{h} bits={bits} order={order} frames={frames}", flush=True)
         rel = float(np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))))
         fg, fw = oracle.derived_features(got), oracle.derived_features(want)
         feat = max(float(np.max(np.abs(fg[k] - fw[k]))) for k in fg)
